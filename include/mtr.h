@@ -1,0 +1,168 @@
+/* mtr.h -- C ABI of libmtr.so: the MI355X-native (HIP, gfx950) rModel draw path.
+ *
+ * The reference (ReplayCoding/mt-renderer) has no FFI: its seam is the Rust API typed over wgpu
+ *     Model::new / Model::set_parts_disp / Model::render      (src/model.rs:36-45, :295, :299-305)
+ *     Texture::new                                            (src/texture.rs:11)
+ *     RendererApp::{setup, render, post_render}               (src/renderer_app_manager.rs:14-32)
+ * and everything below `wgpu::RenderPass::draw_indexed` happens inside a GPU driver.  This header
+ * is what a Rust `mtr-sys` crate would bind: plain pointers and sizes, an
+ * int32 status return, out-parameters last, no unwinding, opaque handles freed by the matching
+ * *_destroy.  The caller owns every host buffer passed in; the library copies at *_create.
+ *
+ * Matrix convention: 16 f32, column-major, M*v (glam::Mat4 bytes, src/bin/modelviewer.rs:217-221).
+ * Threading: one host thread per mtr_device at a time (externally synchronised), as the reference's
+ * single winit thread.  There is no CPU fallback: every entry point needs a HIP device.
+ */
+#ifndef MTR_H
+#define MTR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTR_ABI_VERSION 1
+
+enum {
+    MTR_OK = 0,
+    MTR_E_INVALID = 1,     /* bad argument / out-of-range offset (reference: panic) */
+    MTR_E_UNSUPPORTED = 2, /* vertex/texture format the reference todo!()s: src/rshader2.rs:519-563, src/rtexture.rs:159 */
+    MTR_E_NOMEM = 3,
+    MTR_E_HIP = 4,         /* a HIP runtime call failed; see mtr_last_error */
+    MTR_E_OVERFLOW = 5     /* internal queue capacity exceeded and could not be grown */
+};
+
+/* vertex element semantics: Position / TexCoord are the only names the reference binds
+ * (src/rshader2.rs:503-507); Joint / Weight are this build's linear-blend-skinning extension */
+enum { MTR_SEM_POSITION = 0, MTR_SEM_TEXCOORD = 1, MTR_SEM_JOINT = 2, MTR_SEM_WEIGHT = 3 };
+
+/* InputElementFormat, numeric values of src/rshader2.rs:73-90 */
+enum {
+    MTR_IEF_F32 = 1, MTR_IEF_F16 = 2, MTR_IEF_S16 = 3, MTR_IEF_U16 = 4, MTR_IEF_S16N = 5,
+    MTR_IEF_U16N = 6, MTR_IEF_S8 = 7, MTR_IEF_U8 = 8, MTR_IEF_S8N = 9, MTR_IEF_U8N = 10,
+    MTR_IEF_SCMP3N = 11, MTR_IEF_UCMP3N = 12, MTR_IEF_U8NL = 13, MTR_IEF_COLOR4N = 14
+};
+
+/* rTexture format ids accepted by TextureFile::format_wgpu (src/rtexture.rs:152-161) */
+enum { MTR_TEX_RGBA8 = 7, MTR_TEX_BC1 = 19, MTR_TEX_BC7 = 42, MTR_TEX_BC7_ALT = 54 };
+
+/* PrimitiveInfo, verbatim 0x38 bytes (src/rmodel.rs:135-171; size test :489) */
+typedef struct mtr_primitive {
+    uint32_t w[14];
+} mtr_primitive;
+
+/* one decoded input-layout element (src/rshader2.rs:425-442): replaces the wgpu::VertexAttribute
+ * list that Shader2File::create_vertex_buffer_elements builds (src/rshader2.rs:496-571) */
+typedef struct mtr_element {
+    uint8_t semantic; /* MTR_SEM_* */
+    uint8_t format;   /* MTR_IEF_* */
+    uint8_t count;
+    uint8_t pad0;
+    uint16_t offset;  /* byte offset inside the vertex (9 bits in the file) */
+    uint16_t pad1;
+} mtr_element;
+
+typedef struct mtr_layout {
+    uint32_t num_elements; /* <= 8 */
+    mtr_element elements[8];
+} mtr_layout;
+
+typedef struct mtr_device mtr_device;
+typedef struct mtr_texture mtr_texture;
+typedef struct mtr_model mtr_model;
+typedef struct mtr_batch mtr_batch;
+typedef struct mtr_frame mtr_frame;
+
+/* per-frame counters (device side, read back by mtr_frame_get_stats) */
+typedef struct mtr_frame_stats {
+    uint64_t tris_in;     /* input triangles, SURVEY 8(d) definition */
+    uint64_t tris_setup;  /* triangles that survived clip / cull / empty-bbox */
+    uint64_t bin_entries; /* (triangle, 32x32 bin) pairs */
+    uint64_t segments;    /* per-bin ordered runs */
+    uint32_t width, height, nbins, ndraws;
+} mtr_frame_stats;
+
+/* stage timings of the last submitted frame, milliseconds, from hipEvents recorded on the
+ * device's stream (enabled by mtr_device_set_profiling) */
+enum { MTR_STAGE_GEOM = 0, MTR_STAGE_SCAN = 1, MTR_STAGE_FILL = 2, MTR_STAGE_TILE = 3, MTR_STAGE_COUNT = 4 };
+
+/* ---- device (replaces wgpu::Device + wgpu::Queue, src/renderer_app_manager.rs:103-115) ---- */
+int32_t mtr_device_create(int32_t hip_device, mtr_device **out);
+/* same, but all work is issued on a caller-owned hipStream_t (e.g. torch's current stream) */
+int32_t mtr_device_create_on_stream(int32_t hip_device, void *hip_stream, mtr_device **out);
+void mtr_device_destroy(mtr_device *dev);
+const char *mtr_last_error(const mtr_device *dev); /* never NULL; dev may be NULL for create errors */
+int32_t mtr_device_set_profiling(mtr_device *dev, int32_t enable);
+int32_t mtr_abi_version(void);
+
+/* ---- Texture::new (src/texture.rs:11-30): level 0 only, 2-D, decoded on upload ---- */
+int32_t mtr_texture_create(mtr_device *dev, uint32_t width, uint32_t height, uint32_t format,
+                           const void *data, size_t len, mtr_texture **out);
+void mtr_texture_destroy(mtr_texture *tex);
+/* decoded RGBA8 texels (row-major, width*height*4 bytes): what the sampler reads */
+int32_t mtr_texture_read_rgba8(mtr_texture *tex, void *out, size_t len);
+
+/* ---- Model::new (src/model.rs:36-293) ----
+ * vertex_buf/index_buf: ModelFile::vertex_buf()/index_buf() (src/rmodel.rs:457-463).
+ * prims: ModelFile::primitives(), one layout / texture slot / debug id per primitive:
+ *   prim_to_texture[p] = index into textures[] or -1 (mat_to_tex, src/model.rs:60-75,167,324)
+ *   prim_debug_id[p]   = boundary_infos[prim.boundary_num()].joint() (src/model.rs:140-141)
+ * parts_disp defaults to all-true with len = nprims (src/model.rs:270). */
+int32_t mtr_model_create(mtr_device *dev, const void *vertex_buf, size_t vertex_len,
+                         const uint16_t *index_buf, size_t index_num, const mtr_primitive *prims,
+                         size_t nprims, const mtr_layout *layouts, const int32_t *prim_to_texture,
+                         mtr_texture *const *textures, size_t ntextures,
+                         const uint32_t *prim_debug_id, mtr_model **out);
+void mtr_model_destroy(mtr_model *model);
+/* Model::set_parts_disp (src/model.rs:295-297) */
+int32_t mtr_model_set_parts_disp(mtr_model *model, const uint8_t *parts_disp, size_t n);
+/* bone palette for linear-blend skinning (build extension; n x 16 f32 column-major, n <= 256) */
+int32_t mtr_model_set_palette(mtr_model *model, const float *mats, size_t n);
+
+/* ---- instance batch ("scheduler" submission): n instances of one model, each
+ * with its own model matrix and (optionally) palette and albedo override, resident in HBM ---- */
+int32_t mtr_batch_create(mtr_device *dev, mtr_model *model, size_t n, const float *model_mats,
+                         const float *palettes /* n * npal * 16 or NULL */, size_t npal,
+                         const int32_t *texture_override /* n entries or NULL */, mtr_batch **out);
+void mtr_batch_destroy(mtr_batch *batch);
+
+/* ---- frame = one render pass (src/bin/modelviewer.rs:190-210: clear colour / clear depth) ---- */
+int32_t mtr_frame_begin(mtr_device *dev, uint32_t width, uint32_t height, const float clear_rgba[4],
+                        float clear_depth, mtr_frame **out);
+/* renders only bins with (bin_index % world) == rank; colour/depth of other bins are untouched.
+ * The sharded colour is exchanged by the caller (RCCL all-gather, see bench.py). */
+int32_t mtr_frame_set_shard(mtr_frame *frame, uint32_t rank, uint32_t world);
+/* Model::render (src/model.rs:299-363) with transform = view_proj (src/bin/modelviewer.rs:217-221) */
+int32_t mtr_frame_draw_model(mtr_frame *frame, mtr_model *model, const float view_proj[16]);
+int32_t mtr_frame_draw_batch(mtr_frame *frame, mtr_batch *batch, const float view_proj[16]);
+/* convenience: host arrays, builds a temporary batch (npal palettes per instance, may be 0) */
+int32_t mtr_frame_draw_instances(mtr_frame *frame, mtr_model *model, const float *model_mats,
+                                 const float *palettes, size_t npal, size_t n,
+                                 const float view_proj[16]);
+/* DebugOverlay::render (src/debug_overlay.rs:202-221): n instanced cubes, no blend, constant colour */
+int32_t mtr_frame_draw_overlay_cubes(mtr_frame *frame, const float camera[16], const float *inst_mats,
+                                     size_t n);
+int32_t mtr_frame_submit(mtr_frame *frame); /* enqueue all kernels; returns without waiting */
+int32_t mtr_frame_wait(mtr_frame *frame);   /* framebuffer complete in HBM; checks device flags */
+int32_t mtr_frame_end(mtr_frame *frame);    /* submit + wait */
+int32_t mtr_frame_read_color(mtr_frame *frame, void *rgba8, size_t len);  /* width*height*4 */
+int32_t mtr_frame_read_depth(mtr_frame *frame, float *depth, size_t count); /* width*height */
+void *mtr_frame_color_devptr(mtr_frame *frame); /* RGBA8 in HBM, row-major */
+void *mtr_frame_depth_devptr(mtr_frame *frame); /* f32 in HBM, row-major */
+int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
+int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
+void mtr_frame_destroy(mtr_frame *frame);
+
+/* ---- unit-test hooks: one stage at a time through the same kernels ---- */
+/* vertex stage of primitive `prim`: clip = M * (skin(position),1) and decoded texcoord for every
+ * vertex in [0, vertex_num); out_clip vertex_num*4 f32, out_uv vertex_num*2 f32 (host memory) */
+int32_t mtr_model_vertex_stage(mtr_model *model, size_t prim, const float M[16], float *out_clip,
+                               float *out_uv);
+/* MT crc32 (src/util/crc.rs:36-50), host side: material-name -> material lookups */
+uint32_t mtr_crc32(const uint8_t *bytes, size_t len, uint32_t init);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

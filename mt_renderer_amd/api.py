@@ -1,0 +1,345 @@
+"""ctypes binding of libmtr.so (include/mtr.h) + a host-side mirror of the reference's interface.
+
+The classes keep the reference's names and argument roles -- ``Texture.new`` (src/texture.rs:11),
+``Model.new`` / ``Model.set_parts_disp`` / ``Model.render`` (src/model.rs:36-45, :295, :299-305) --
+with ``wgpu::Device`` / ``wgpu::RenderPass`` replaced by :class:`Device` / :class:`Frame`.
+
+There is NO CPU fallback here: if libmtr.so is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .scene import ModelData, TextureData
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmtr.so")
+
+MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
+STAGE_NAMES = ("geom", "scan", "fill", "tile")
+
+# every symbol include/mtr.h declares (tests check that the library exports each one)
+EXPORTED_SYMBOLS = [
+    "mtr_abi_version", "mtr_device_create", "mtr_device_create_on_stream", "mtr_device_destroy", "mtr_last_error",
+    "mtr_device_set_profiling", "mtr_texture_create", "mtr_texture_destroy", "mtr_texture_read_rgba8",
+    "mtr_model_create", "mtr_model_destroy", "mtr_model_set_parts_disp", "mtr_model_set_palette",
+    "mtr_batch_create", "mtr_batch_destroy", "mtr_frame_begin", "mtr_frame_set_shard", "mtr_frame_draw_model",
+    "mtr_frame_draw_batch", "mtr_frame_draw_instances", "mtr_frame_draw_overlay_cubes", "mtr_frame_submit",
+    "mtr_frame_wait", "mtr_frame_end", "mtr_frame_read_color", "mtr_frame_read_depth", "mtr_frame_color_devptr",
+    "mtr_frame_depth_devptr", "mtr_frame_get_stats", "mtr_frame_get_timings", "mtr_frame_destroy",
+    "mtr_model_vertex_stage", "mtr_crc32",
+]
+
+
+class MtrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mtr error {code}: {msg}")
+        self.code = code
+
+
+class _Primitive(C.Structure):
+    _fields_ = [("w", C.c_uint32 * 14)]
+
+
+class _Element(C.Structure):
+    _fields_ = [("semantic", C.c_uint8), ("format", C.c_uint8), ("count", C.c_uint8), ("pad0", C.c_uint8),
+                ("offset", C.c_uint16), ("pad1", C.c_uint16)]
+
+
+class _Layout(C.Structure):
+    _fields_ = [("num_elements", C.c_uint32), ("elements", _Element * 8)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
+                ("segments", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("nbins", C.c_uint32),
+                ("ndraws", C.c_uint32)]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the HIP draw path)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
+    sig = {
+        "mtr_abi_version": (i32, []),
+        "mtr_device_create": (i32, [i32, C.POINTER(vp)]),
+        "mtr_device_create_on_stream": (i32, [i32, vp, C.POINTER(vp)]),
+        "mtr_device_destroy": (None, [vp]),
+        "mtr_last_error": (C.c_char_p, [vp]),
+        "mtr_device_set_profiling": (i32, [vp, i32]),
+        "mtr_texture_create": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(vp)]),
+        "mtr_texture_destroy": (None, [vp]),
+        "mtr_texture_read_rgba8": (i32, [vp, vp, sz]),
+        "mtr_model_create": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, sz, vp, C.POINTER(vp)]),
+        "mtr_model_destroy": (None, [vp]),
+        "mtr_model_set_parts_disp": (i32, [vp, vp, sz]),
+        "mtr_model_set_palette": (i32, [vp, vp, sz]),
+        "mtr_batch_create": (i32, [vp, vp, sz, vp, vp, sz, vp, C.POINTER(vp)]),
+        "mtr_batch_destroy": (None, [vp]),
+        "mtr_frame_begin": (i32, [vp, u32, u32, vp, C.c_float, C.POINTER(vp)]),
+        "mtr_frame_set_shard": (i32, [vp, u32, u32]),
+        "mtr_frame_draw_model": (i32, [vp, vp, vp]),
+        "mtr_frame_draw_batch": (i32, [vp, vp, vp]),
+        "mtr_frame_draw_instances": (i32, [vp, vp, vp, vp, sz, sz, vp]),
+        "mtr_frame_draw_overlay_cubes": (i32, [vp, vp, vp, sz]),
+        "mtr_frame_submit": (i32, [vp]),
+        "mtr_frame_wait": (i32, [vp]),
+        "mtr_frame_end": (i32, [vp]),
+        "mtr_frame_read_color": (i32, [vp, vp, sz]),
+        "mtr_frame_read_depth": (i32, [vp, vp, sz]),
+        "mtr_frame_color_devptr": (vp, [vp]),
+        "mtr_frame_depth_devptr": (vp, [vp]),
+        "mtr_frame_get_stats": (i32, [vp, C.POINTER(FrameStats)]),
+        "mtr_frame_get_timings": (i32, [vp, C.POINTER(C.c_float * 4)]),
+        "mtr_frame_destroy": (None, [vp]),
+        "mtr_model_vertex_stage": (i32, [vp, sz, vp, vp, vp]),
+        "mtr_crc32": (u32, [vp, sz, u32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None) -> np.ndarray:
+    r = np.ascontiguousarray(a, dtype=np.float32)
+    return r if shape is None else r.reshape(shape)
+
+
+def crc32(data: bytes, init: int = 0xFFFFFFFF) -> int:
+    buf = np.frombuffer(data + b"\0", dtype=np.uint8)
+    return int(lib.mtr_crc32(_p(buf), len(data), init))
+
+
+class Device:
+    """Stands where ``wgpu::Device`` + ``wgpu::Queue`` do (src/renderer_app_manager.rs:103-115)."""
+
+    def __init__(self, hip_device: int = 0, stream: Optional[int] = None):
+        h = C.c_void_p()
+        rc = lib.mtr_device_create_on_stream(hip_device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc:
+            raise MtrError(rc, (lib.mtr_last_error(None) or b"").decode())
+        self._h = h
+
+    def check(self, rc: int):
+        if rc:
+            raise MtrError(rc, (lib.mtr_last_error(self._h) or b"").decode())
+
+    def set_profiling(self, on: bool):
+        self.check(lib.mtr_device_set_profiling(self._h, 1 if on else 0))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mtr_device_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Texture:
+    def __init__(self, dev: Device, h):
+        self.dev, self._h = dev, h
+
+    @staticmethod
+    def new(dev: Device, resource: TextureData) -> "Texture":
+        """Texture::new(device, queue, resource) -- src/texture.rs:11."""
+        h = C.c_void_p()
+        buf = np.frombuffer(resource.data, dtype=np.uint8)
+        dev.check(lib.mtr_texture_create(dev._h, resource.width, resource.height, resource.fmt, _p(buf), buf.size,
+                                         C.byref(h)))
+        t = Texture(dev, h)
+        t.width, t.height = resource.width, resource.height
+        return t
+
+    def read_rgba8(self) -> np.ndarray:
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self.dev.check(lib.mtr_texture_read_rgba8(self._h, _p(out), out.size))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.mtr_texture_destroy(self._h)
+            self._h = None
+
+
+class Model:
+    def __init__(self, dev: Device, h, textures: List[Texture], md: ModelData):
+        self.dev, self._h, self.textures, self.md = dev, h, textures, md
+
+    @staticmethod
+    def new(dev: Device, md: ModelData) -> "Model":
+        """Model::new(model_file, material_file, shader2, ...) -- src/model.rs:36-45.  ``md`` carries what
+        those three parsed files contribute to the draw path."""
+        textures = [Texture.new(dev, t) for t in md.textures]
+        vb = np.ascontiguousarray(md.vertex_buf, dtype=np.uint8)
+        ib = np.ascontiguousarray(md.index_buf, dtype=np.uint16)
+        pr = np.ascontiguousarray(md.prims, dtype=np.uint8).reshape(-1, 0x38)
+        lays = (_Layout * len(md.layouts))()
+        for i, els in enumerate(md.layouts):
+            if len(els) > 8:
+                raise MtrError(MTR_E_INVALID, "more than 8 layout elements")
+            lays[i].num_elements = len(els)
+            for j, (sem, fmt, cnt, off) in enumerate(els):
+                e = lays[i].elements[j]
+                e.semantic, e.format, e.count, e.offset = sem, fmt, cnt, off
+        p2t = np.ascontiguousarray(md.prim_to_texture, dtype=np.int32)
+        did = np.ascontiguousarray(md.prim_debug_id, dtype=np.uint32)
+        th = (C.c_void_p * max(1, len(textures)))(*[t._h for t in textures])
+        h = C.c_void_p()
+        dev.check(lib.mtr_model_create(dev._h, _p(vb), vb.size, _p(ib), ib.size, _p(pr), pr.shape[0], C.cast(lays, C.c_void_p),
+                                       _p(p2t), C.cast(th, C.c_void_p), len(textures), _p(did), C.byref(h)))
+        m = Model(dev, h, textures, md)
+        pd = np.ascontiguousarray(md.parts_disp, dtype=np.uint8)
+        if pd.size != pr.shape[0] or not pd.all():
+            m.set_parts_disp(pd)
+        return m
+
+    def set_parts_disp(self, parts_disp: Sequence[bool]):
+        """Model::set_parts_disp -- src/model.rs:295."""
+        pd = np.ascontiguousarray(parts_disp, dtype=np.uint8)
+        self.dev.check(lib.mtr_model_set_parts_disp(self._h, _p(pd), pd.size))
+
+    def set_palette(self, mats: Optional[np.ndarray]):
+        if mats is None:
+            self.dev.check(lib.mtr_model_set_palette(self._h, None, 0))
+        else:
+            m = _f32(mats, (-1, 16))
+            self.dev.check(lib.mtr_model_set_palette(self._h, _p(m), m.shape[0]))
+
+    def render(self, frame: "Frame", view_proj: np.ndarray):
+        """Model::render(rpass, queue, transform_bind_group, debug_overlay) -- src/model.rs:299-305; the
+        transform uniform (src/bin/modelviewer.rs:217-221) is passed directly."""
+        frame.draw_model(self, view_proj)
+
+    def vertex_stage(self, prim: int, M: np.ndarray):
+        from .scene import unpack_primitive
+        nv = unpack_primitive(self.md.prims[prim])["vertex_num"]
+        clip = np.zeros((nv, 4), dtype=np.float32)
+        uv = np.zeros((nv, 2), dtype=np.float32)
+        Mf = _f32(M, 16)
+        self.dev.check(lib.mtr_model_vertex_stage(self._h, prim, _p(Mf), _p(clip), _p(uv)))
+        return clip, uv
+
+    def close(self):
+        if self._h:
+            lib.mtr_model_destroy(self._h)
+            self._h = None
+        for t in self.textures:
+            t.close()
+        self.textures = []
+
+
+class Batch:
+    """n instances of one Model resident in HBM (the build's scheduler submission)."""
+
+    def __init__(self, dev: Device, model: Model, model_mats: np.ndarray, palettes: Optional[np.ndarray] = None,
+                 texture_override: Optional[Sequence[int]] = None):
+        mm = _f32(model_mats, (-1, 16))
+        n = mm.shape[0]
+        pal, npal = None, 0
+        if palettes is not None:
+            pal = _f32(palettes).reshape(n, -1, 16)
+            npal = pal.shape[1]
+        to = None if texture_override is None else np.ascontiguousarray(texture_override, dtype=np.int32)
+        h = C.c_void_p()
+        dev.check(lib.mtr_batch_create(dev._h, model._h, n, _p(mm), _p(pal), npal, _p(to), C.byref(h)))
+        self.dev, self._h, self.n, self.model = dev, h, n, model
+
+    def close(self):
+        if self._h:
+            lib.mtr_batch_destroy(self._h)
+            self._h = None
+
+
+class Frame:
+    """One render pass: clear colour / depth as in src/bin/modelviewer.rs:190-210 (white, 1.0)."""
+
+    def __init__(self, dev: Device, width: int, height: int, clear_rgba=(1.0, 1.0, 1.0, 1.0), clear_depth: float = 1.0):
+        c = _f32(clear_rgba, 4)
+        h = C.c_void_p()
+        dev.check(lib.mtr_frame_begin(dev._h, width, height, _p(c), clear_depth, C.byref(h)))
+        self.dev, self._h, self.w, self.h = dev, h, width, height
+
+    def set_shard(self, rank: int, world: int):
+        self.dev.check(lib.mtr_frame_set_shard(self._h, rank, world))
+
+    def draw_model(self, model: Model, view_proj: np.ndarray):
+        vp = _f32(view_proj, 16)
+        self.dev.check(lib.mtr_frame_draw_model(self._h, model._h, _p(vp)))
+
+    def draw_batch(self, batch: Batch, view_proj: np.ndarray):
+        vp = _f32(view_proj, 16)
+        self.dev.check(lib.mtr_frame_draw_batch(self._h, batch._h, _p(vp)))
+
+    def draw_instances(self, model: Model, view_proj: np.ndarray, model_mats: np.ndarray,
+                       palettes: Optional[np.ndarray] = None):
+        vp = _f32(view_proj, 16)
+        mm = _f32(model_mats, (-1, 16))
+        pal, npal = None, 0
+        if palettes is not None:
+            pal = _f32(palettes).reshape(mm.shape[0], -1, 16)
+            npal = pal.shape[1]
+        self.dev.check(lib.mtr_frame_draw_instances(self._h, model._h, _p(mm), _p(pal), npal, mm.shape[0], _p(vp)))
+
+    def draw_overlay_cubes(self, camera: np.ndarray, inst_mats: np.ndarray):
+        cam = _f32(camera, 16)
+        im = _f32(inst_mats, (-1, 16))
+        self.dev.check(lib.mtr_frame_draw_overlay_cubes(self._h, _p(cam), _p(im), im.shape[0]))
+
+    def submit(self):
+        self.dev.check(lib.mtr_frame_submit(self._h))
+
+    def wait(self):
+        self.dev.check(lib.mtr_frame_wait(self._h))
+
+    def end(self):
+        self.dev.check(lib.mtr_frame_end(self._h))
+
+    def color(self) -> np.ndarray:
+        out = np.zeros((self.h, self.w, 4), dtype=np.uint8)
+        self.dev.check(lib.mtr_frame_read_color(self._h, _p(out), out.size))
+        return out
+
+    def depth(self) -> np.ndarray:
+        out = np.zeros((self.h, self.w), dtype=np.float32)
+        self.dev.check(lib.mtr_frame_read_depth(self._h, _p(out), out.size))
+        return out
+
+    def color_devptr(self) -> int:
+        return int(lib.mtr_frame_color_devptr(self._h) or 0)
+
+    def stats(self) -> dict:
+        s = FrameStats()
+        self.dev.check(lib.mtr_frame_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def timings_ms(self) -> dict:
+        ms = (C.c_float * 4)()
+        self.dev.check(lib.mtr_frame_get_timings(self._h, C.byref(ms)))
+        return {STAGE_NAMES[i]: float(ms[i]) for i in range(4)}
+
+    def close(self):
+        if self._h:
+            lib.mtr_frame_destroy(self._h)
+            self._h = None

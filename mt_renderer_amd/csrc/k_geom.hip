@@ -1,0 +1,313 @@
+// k_geom.hip -- fused geometry stage of the rModel draw path (gfx950, wave64).
+//
+// One wave = one "chunk": 64 consecutive index-buffer positions of one primitive (2 halo + 62 new).
+// lane = strip position.  Per lane: index fetch, vertex fetch + decode, linear-blend skinning
+// against the LDS-staged palette, clip = M*(q,1), perspective divide, viewport, 1/256-px snap.
+// Triangle (l-2, l-1, l) is assembled by lane l from its neighbours' registers (wave shuffles);
+// primitive restart (0xFFFF, src/model.rs:251) and strip parity come from one wave ballot.
+// Survivors of trivial reject / near clip / back-face cull / empty-bbox are compacted with
+// ballot + popcount into ONE contiguous, submission-ordered run of records per wave, and the
+// (triangle -> 32x32 bin) counts are accumulated with one 64-bit atomic per (wave, bin) group.
+//
+// Replaces everything between `rpass.draw_indexed` (src/model.rs:357-361) and the rasteriser.
+#include "geom_common.h"
+
+namespace mtr {
+
+struct PV {  // projected vertex
+    int32_t X, Y;
+    float z, iw, up, vp;
+    uint32_t flags;  // bit0 valid index, bit1 projectable, bits 2..7 clip outcode
+};
+
+enum { OC_XN = 1, OC_XP = 2, OC_YN = 4, OC_YP = 8, OC_ZN = 16, OC_ZP = 32 };
+
+__device__ __forceinline__ uint32_t outcode(const VOut& c) {
+    uint32_t oc = 0;
+    if (c.x < -c.w) oc |= OC_XN;
+    if (c.x > c.w) oc |= OC_XP;
+    if (c.y < -c.w) oc |= OC_YN;
+    if (c.y > c.w) oc |= OC_YP;
+    if (c.z < 0.0f) oc |= OC_ZN;
+    if (c.z > c.w) oc |= OC_ZP;
+    return oc;
+}
+
+// perspective divide + viewport (WebGPU: y down, depth range [0,1]) + snap; SPEC.md "projection"
+__device__ __forceinline__ PV project(const VOut& c, uint32_t W, uint32_t H) {
+    PV p;
+    p.X = 0; p.Y = 0; p.z = 0.0f; p.iw = 0.0f; p.up = 0.0f; p.vp = 0.0f; p.flags = 0;
+    if (!(c.w > 0.0f)) return p;
+    float iw = 1.0f / c.w;
+    float xn = c.x * iw, yn = c.y * iw, zn = c.z * iw;
+    float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+    float xf = fmaf(xn, hw, hw);
+    float yf = fmaf(-yn, hh, hh);
+    if (!(fabsf(xf) <= MTR_GUARD_BAND && fabsf(yf) <= MTR_GUARD_BAND)) return p;
+    p.flags = 2;
+    p.X = (int32_t)rintf(xf * 256.0f);
+    p.Y = (int32_t)rintf(yf * 256.0f);
+    p.z = zn;
+    p.iw = iw;
+    p.up = c.u * iw;
+    p.vp = c.v * iw;
+    return p;
+}
+
+struct Rec {
+    RecA a;
+    RecB b;
+    RecHdr h;
+};
+
+// back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill
+__device__ __forceinline__ bool setup_tri(const PV& a, const PV& b, const PV& c, uint32_t W, uint32_t H, uint32_t mat,
+                                          Rec& r) {
+    if (!((a.flags & b.flags & c.flags) & 2)) return false;
+    long long A2 = (long long)(c.X - a.X) * (long long)(b.Y - a.Y) - (long long)(b.X - a.X) * (long long)(c.Y - a.Y);
+    if (A2 <= 0) return false;
+    int32_t xmin = min(a.X, min(b.X, c.X)), xmax = max(a.X, max(b.X, c.X));
+    int32_t ymin = min(a.Y, min(b.Y, c.Y)), ymax = max(a.Y, max(b.Y, c.Y));
+    int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
+    int32_t py0 = (ymin + 127) >> 8, py1 = (ymax - 128) >> 8;
+    px0 = max(px0, 0); py0 = max(py0, 0);
+    px1 = min(px1, (int32_t)W - 1); py1 = min(py1, (int32_t)H - 1);
+    if (px0 > px1 || py0 > py1) return false;
+    r.h.bx0 = (uint16_t)(px0 >> MTR_BIN_SHIFT); r.h.bx1 = (uint16_t)(px1 >> MTR_BIN_SHIFT);
+    r.h.by0 = (uint16_t)(py0 >> MTR_BIN_SHIFT); r.h.by1 = (uint16_t)(py1 >> MTR_BIN_SHIFT);
+    r.a.X0 = a.X; r.a.Y0 = a.Y; r.a.X1 = b.X; r.a.Y1 = b.Y; r.a.X2 = c.X; r.a.Y2 = c.Y;
+    r.a.z0 = a.z; r.a.z1 = b.z; r.a.z2 = c.z; r.a.mat = mat; r.a.pad0 = 0; r.a.pad1 = 0;
+    r.b.iw0 = a.iw; r.b.iw1 = b.iw; r.b.iw2 = c.iw;
+    r.b.up0 = a.up; r.b.up1 = b.up; r.b.up2 = c.up;
+    r.b.vp0 = a.vp; r.b.vp1 = b.vp; r.b.vp2 = c.vp;
+    r.b.pad0 = r.b.pad1 = r.b.pad2 = 0.0f;
+    return true;
+}
+
+__device__ __forceinline__ VOut clip_lerp(const VOut& in, const VOut& out) {  // in.z >= 0 > out.z
+    float t = in.z / (in.z - out.z);
+    VOut r;
+    r.x = fmaf(t, out.x - in.x, in.x);
+    r.y = fmaf(t, out.y - in.y, in.y);
+    r.z = 0.0f;
+    r.w = fmaf(t, out.w - in.w, in.w);
+    r.u = fmaf(t, out.u - in.u, in.u);
+    r.v = fmaf(t, out.v - in.v, in.v);
+    return r;
+}
+
+__device__ __forceinline__ void compose_matrix(const GeomParams& P, uint32_t inst, float (&M)[16]) {
+    if (P.model_mats) {
+        const float* B = P.model_mats + (size_t)inst * 16;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) a = fmaf(P.vp[k * 4 + i], B[c * 4 + k], a);
+                M[c * 4 + i] = a;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) M[i] = P.vp[i];
+    }
+}
+
+__device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst, float* s_pal) {
+    if (P.palettes && P.npal) {
+        const float4* src = reinterpret_cast<const float4*>(P.palettes + (size_t)inst * P.pal_stride);
+        for (uint32_t i = threadIdx.x; i < P.npal * 4; i += blockDim.x) reinterpret_cast<float4*>(s_pal)[i] = src[i];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_geom(GeomParams P) {
+    extern __shared__ __align__(16) float s_pal[];
+    __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t inst = blockIdx.y;
+    stage_palette(P, inst, s_pal);
+    // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of
+    // chunks so neighbouring strips (which share a vertex row) hit the same L2.  Speed only.
+    const uint32_t nblk = gridDim.x;
+    const uint32_t per = (nblk + 7) / 8;
+    const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const uint32_t c = blk * 4 + wave;
+    if (blk >= nblk || c >= P.nchunks) return;
+
+    float M[16];
+    compose_matrix(P, inst, M);
+    const DChunk ch = P.chunks[c];
+    const DPrim pr = P.prims[ch.prim];
+    const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
+    const uint32_t mat = P.mat_base + inst * P.mat_inst_stride + ch.prim;
+    const uint32_t W = P.fb.W, H = P.fb.H;
+    const bool skinned = pr.skinnable && P.palettes && P.npal;
+    const bool strip = pr.topology == 4;
+
+    // ---- index fetch (Uint16, src/model.rs:307) ----
+    const int32_t p = (int32_t)ch.start - 2 + (int32_t)lane;
+    const bool in_range = p >= 0 && (uint32_t)p < pr.index_num;
+    const uint32_t idx = in_range ? (uint32_t)P.ibuf[pr.index_ofs + (uint32_t)p] : 0xFFFFu;
+    const bool is_restart = !in_range || (strip && idx == 0xFFFFu);
+    const uint32_t vid = idx + pr.index_base;  // base_vertex = index_base, src/model.rs:359
+    const bool vvalid = !is_restart && vid < pr.vertex_num;
+
+    // ---- vertex stage ----
+    PV me;
+    me.X = 0; me.Y = 0; me.z = 0.0f; me.iw = 0.0f; me.up = 0.0f; me.vp = 0.0f; me.flags = 0;
+    if (vvalid) {
+        VOut v = shade_vertex(P.vbuf, pr, vid, M, s_pal, P.npal, skinned);
+        me = project(v, W, H);
+        me.flags |= 1u | (outcode(v) << 2);
+    }
+
+    // ---- strip assembly: which lanes complete a triangle, and its winding parity ----
+    const uint64_t R = __ballot(is_restart);
+    const uint64_t below = R & ((1ull << lane) - 1ull);
+    uint32_t q = 0;  // indices since the last restart, this one included
+    if (!is_restart) q = below ? lane - (63u - (uint32_t)__clzll((long long)below)) : ch.q_before + lane + 1u;
+    bool tri, odd;
+    if (strip) {
+        tri = q >= 3 && lane >= 2;
+        odd = ((q - 3) & 1) != 0;
+    } else {
+        tri = lane >= 2 && in_range && ((uint32_t)p % 3u == 2u);
+        odd = false;
+    }
+
+    PV v1, v2;  // lanes l-1 and l-2
+    v1.X = __shfl_up(me.X, 1); v2.X = __shfl_up(me.X, 2);
+    v1.Y = __shfl_up(me.Y, 1); v2.Y = __shfl_up(me.Y, 2);
+    v1.z = __shfl_up(me.z, 1); v2.z = __shfl_up(me.z, 2);
+    v1.iw = __shfl_up(me.iw, 1); v2.iw = __shfl_up(me.iw, 2);
+    v1.up = __shfl_up(me.up, 1); v2.up = __shfl_up(me.up, 2);
+    v1.vp = __shfl_up(me.vp, 1); v2.vp = __shfl_up(me.vp, 2);
+    v1.flags = __shfl_up(me.flags, 1); v2.flags = __shfl_up(me.flags, 2);
+    const uint32_t vid1 = __shfl_up(vid, 1), vid2 = __shfl_up(vid, 2);
+
+    // triangle i of a strip = (v_i, v_{i+1}, v_{i+2}) for even i, (v_i, v_{i+2}, v_{i+1}) for odd i
+    const PV& ta = v2;
+    const PV& tb = odd ? me : v1;
+    const PV& tc = odd ? v1 : me;
+
+    Rec r0, r1;
+    uint32_t n_out = 0;
+    const uint32_t f_and = ta.flags & tb.flags & tc.flags, f_or = ta.flags | tb.flags | tc.flags;
+    tri = tri && (f_and & 1u);            // every vertex inside the bound slice (SPEC.md)
+    tri = tri && ((f_and >> 2) == 0);     // trivial frustum reject
+    if (tri) {
+        if (!((f_or >> 2) & OC_ZN)) {
+            if (setup_tri(ta, tb, tc, W, H, mat, r0)) n_out = 1;
+        } else {
+            // near-plane clip (z >= 0): rare, re-shades the three vertices in clip space
+            const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
+            VOut cv[3] = {shade_vertex(P.vbuf, pr, ia, M, s_pal, P.npal, skinned),
+                          shade_vertex(P.vbuf, pr, ib, M, s_pal, P.npal, skinned),
+                          shade_vertex(P.vbuf, pr, ic, M, s_pal, P.npal, skinned)};
+            VOut poly[4];
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const VOut& pp = cv[i];
+                const VOut& qq = cv[(i + 1) % 3];
+                bool pin = !(pp.z < 0.0f), qin = !(qq.z < 0.0f);
+                if (pin) poly[n++] = pp;
+                if (pin != qin) poly[n++] = pin ? clip_lerp(pp, qq) : clip_lerp(qq, pp);
+            }
+            if (n >= 3) {
+                PV q0 = project(poly[0], W, H), q1 = project(poly[1], W, H), q2 = project(poly[2], W, H);
+                bool s0 = setup_tri(q0, q1, q2, W, H, mat, r0);
+                bool s1 = false;
+                if (n == 4) {
+                    PV q3 = project(poly[3], W, H);
+                    s1 = setup_tri(q0, q2, q3, W, H, mat, s0 ? r1 : r0);
+                }
+                n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
+            }
+        }
+    }
+
+    // ---- wave compaction: one contiguous, ordered run of records per chunk ----
+    const uint64_t b1 = __ballot(n_out >= 1), b2 = __ballot(n_out == 2);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t rank = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+    uint32_t total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    uint32_t base = 0;
+    if (lane == 0) {
+        if (total) {
+            base = atomicAdd(&P.fb.counters[CTR_RECORDS], total);
+            if (base + total > P.fb.rec_cap) {  // cannot happen: rec_cap is the hard upper bound
+                atomicOr(&P.fb.counters[CTR_OVERFLOW], 1u);
+                total = 0;
+            }
+        }
+        ChunkInfo ci = {base, total};
+        P.fb.chunk_info[gid] = ci;
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    total = __builtin_amdgcn_readfirstlane(total);
+    if (total == 0) return;
+    if (n_out >= 1) {
+        P.fb.rec_a[base + rank] = r0.a;
+        P.fb.rec_hdr[base + rank] = r0.h;
+        if (pr.has_uv) P.fb.rec_b[base + rank] = r0.b;
+        s_hdr[wave][rank] = r0.h;
+    }
+    if (n_out == 2) {
+        P.fb.rec_a[base + rank + 1] = r1.a;
+        P.fb.rec_hdr[base + rank + 1] = r1.h;
+        if (pr.has_uv) P.fb.rec_b[base + rank + 1] = r1.b;
+        s_hdr[wave][rank + 1] = r1.h;
+    }
+    // s_hdr[wave] is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- triangle -> bin counting: one atomic per (wave, bin) group ----
+    for (uint32_t round = 0; round * 64 < total; ++round) {
+        const uint32_t j = round * 64 + lane;
+        const bool act = j < total;
+        RecHdr h = {0, 0, 0, 0};
+        if (act) h = s_hdr[wave][j];
+        for_each_bin_group(h, act, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world,
+                           [&](uint32_t bin, uint64_t m, bool hit) {
+                               if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
+                                   atomicAdd(&P.fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
+                           });
+    }
+}
+
+// vertex stage alone (unit-parity hook: mtr_model_vertex_stage)
+__global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t prim, float* out_clip, float* out_uv) {
+    extern __shared__ __align__(16) float s_pal[];
+    stage_palette(P, 0, s_pal);
+    float M[16];
+    compose_matrix(P, 0, M);
+    const DPrim pr = P.prims[prim];
+    const bool skinned = pr.skinnable && P.palettes && P.npal;
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= pr.vertex_num) return;
+    VOut o = shade_vertex(P.vbuf, pr, v, M, s_pal, P.npal, skinned);
+    out_clip[4 * v + 0] = o.x; out_clip[4 * v + 1] = o.y; out_clip[4 * v + 2] = o.z; out_clip[4 * v + 3] = o.w;
+    out_uv[2 * v + 0] = o.u; out_uv[2 * v + 1] = o.v;
+}
+
+}  // namespace mtr
+
+void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
+    if (p.nchunks == 0 || p.ninst == 0) return;
+    uint32_t nblk = (p.nchunks + 3) / 4;
+    nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
+    dim3 grid(nblk, p.ninst);
+    size_t lds = (size_t)p.npal * 64;
+    hipLaunchKernelGGL(mtr::k_geom, grid, dim3(256), lds, s, p);
+}
+
+void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s) {
+    // vertex_num is 16 bits (src/rmodel.rs:218-220): at most 256 blocks
+    hipLaunchKernelGGL(mtr::k_vertex_stage, dim3(256), dim3(256), (size_t)p.npal * 64, s, p, prim, out_clip, out_uv);
+}

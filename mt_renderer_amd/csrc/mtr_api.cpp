@@ -1,0 +1,926 @@
+// mtr_api.cpp -- host side of libmtr.so: handles, validation, HBM residency, launch orchestration.
+// Mirrors the reference's object model: Texture::new (src/texture.rs:11), Model::new / render /
+// set_parts_disp (src/model.rs:36-363) and the render pass of src/bin/modelviewer.rs:190-234.
+#include "../../include/mtr.h"
+#include "mtr_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct ColorDepth {
+    uint32_t w, h;
+    uint8_t* color;
+    float* depth;
+    uint32_t* counters;
+};
+
+}  // namespace
+
+struct mtr_device {
+    int hip_dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    std::string err;
+    // grow-only intermediate buffers, shared by every frame of this device (frames execute in
+    // stream order, so a later frame never overlaps an earlier one's use of them)
+    RecHdr* rec_hdr = nullptr;
+    RecA* rec_a = nullptr;
+    RecB* rec_b = nullptr;
+    ChunkInfo* chunk_info = nullptr;
+    uint32_t rec_cap = 0, chunk_cap = 0;
+    unsigned long long* bin_count = nullptr;
+    unsigned long long* bin_fill = nullptr;
+    uint32_t* bin_start = nullptr;
+    uint32_t* seg_start = nullptr;
+    uint32_t bin_cap = 0;
+    uint32_t* entries = nullptr;
+    Seg* segs = nullptr;
+    uint32_t entry_cap = 0, seg_cap = 0;
+    DMat* mats = nullptr;
+    uint32_t mat_cap = 0;
+    std::vector<ColorDepth> free_fb;
+    mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
+};
+
+struct mtr_texture {
+    mtr_device* dev;
+    uint32_t w, h, fmt;
+    uint8_t* d_rgba;
+};
+
+struct mtr_model {
+    mtr_device* dev;
+    uint8_t* d_vbuf = nullptr;
+    uint16_t* d_ibuf = nullptr;
+    DPrim* d_prims = nullptr;
+    DChunk* d_chunks = nullptr;
+    float* d_palette = nullptr;
+    uint32_t npal = 0;
+    std::vector<DPrim> prims;
+    std::vector<uint16_t> indices;
+    std::vector<uint32_t> run;  // consecutive non-restart indices ending at each position
+    std::vector<uint8_t> parts_disp;
+    std::vector<int32_t> prim_to_texture;
+    std::vector<mtr_texture*> textures;
+    std::vector<uint32_t> debug_rgba8;
+    std::vector<DChunk> chunks;
+    uint64_t ntris_visible = 0;
+    bool chunks_dirty = true;
+    size_t vertex_len = 0;
+};
+
+struct mtr_batch {
+    mtr_device* dev;
+    mtr_model* model;
+    uint32_t n = 0;
+    float* d_model_mats = nullptr;
+    float* d_palettes = nullptr;
+    uint32_t npal = 0;
+    std::vector<int32_t> tex_override;
+};
+
+struct BatchDeleter {
+    void operator()(mtr_batch* b) const { mtr_batch_destroy(b); }
+};
+
+struct Draw {
+    mtr_model* model;
+    const float* d_model_mats;  // nullptr: M = view_proj
+    const float* d_palettes;
+    uint32_t npal, pal_stride, ninst;
+    float vp[16];
+    std::vector<int32_t> tex_override;  // per instance or empty
+    int shader_override;                // -1 or MTR_SH_CONST (overlay)
+    uint32_t const_rgba8;
+    bool blend;
+    std::unique_ptr<mtr_batch, BatchDeleter> owned_batch;
+};
+
+struct mtr_frame {
+    mtr_device* dev;
+    uint32_t w, h;
+    uint32_t clear_rgba8;
+    float clear_depth;
+    ColorDepth fb;
+    uint32_t shard_rank = 0, shard_world = 1;
+    std::vector<Draw> draws;
+    std::vector<DMat> mats_host;  // kept alive until the async upload has certainly been consumed
+    bool submitted = false, waited = false;
+    mtr_frame_stats stats{};
+    hipEvent_t ev[MTR_STAGE_COUNT + 1] = {};
+    bool have_events = false;
+    float ms[MTR_STAGE_COUNT] = {};
+};
+
+namespace {
+
+int32_t fail(mtr_device* d, int32_t code, const std::string& msg) {
+    if (d) d->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHK(dev, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail((dev), MTR_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+uint32_t quant8(float x) {
+    if (!(x > 0.0f)) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    return (uint32_t)std::rint(x * 255.0f);
+}
+
+uint32_t pack_rgba8(const float c[4]) {
+    return quant8(c[0]) | (quant8(c[1]) << 8) | (quant8(c[2]) << 16) | (quant8(c[3]) << 24);
+}
+
+// src/shaders/debug_ids.wgsl:23-44
+const uint8_t kDebugPalette[20][3] = {
+    {215, 62, 103}, {95, 190, 80},  {133, 95, 213},  {180, 184, 53},  {213, 87, 180}, {72, 138, 55},  {145, 79, 158},
+    {91, 196, 153}, {206, 78, 55},  {74, 174, 209},  {225, 133, 58},  {92, 122, 198}, {207, 162, 81}, {188, 144, 216},
+    {152, 173, 92}, {161, 71, 103}, {53, 133, 98},   {225, 131, 152}, {111, 111, 40}, {162, 99, 55},
+};
+
+// bytes a float-class element reads, 0 = not in the reference's table (src/rshader2.rs:516-564)
+uint32_t elem_bytes(uint8_t fmt, uint8_t cnt) {
+    switch (fmt) {
+    case MTR_IEF_U8N: return cnt == 1 ? 2 : cnt == 4 ? 4 : 0;
+    case MTR_IEF_S8N: return cnt == 1 ? 2 : (cnt == 3 || cnt == 4) ? 4 : 0;
+    case MTR_IEF_S16N: return cnt == 1 ? 4 : cnt == 3 ? 8 : 0;
+    case MTR_IEF_F16: return cnt == 2 ? 4 : 0;
+    case MTR_IEF_F32: return cnt == 3 ? 12 : 0;
+    case MTR_IEF_U8NL: return cnt == 3 ? 4 : 0;
+    default: return 0;
+    }
+}
+
+template <class T>
+int32_t dev_alloc(mtr_device* d, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(d, MTR_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return MTR_OK;
+}
+
+template <class T>
+int32_t dev_grow(mtr_device* d, T** p, uint32_t* cap, size_t need) {
+    if (need <= *cap && *p) return MTR_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    int32_t rc = dev_alloc(d, p, need);
+    if (rc) return rc;
+    *cap = (uint32_t)need;
+    return MTR_OK;
+}
+
+int32_t set_device(mtr_device* d) {
+    HIPCHK(d, hipSetDevice(d->hip_dev));
+    return MTR_OK;
+}
+
+void rebuild_chunks(mtr_model* m) {
+    m->chunks.clear();
+    m->ntris_visible = 0;
+    for (size_t p = 0; p < m->prims.size(); p++) {
+        const DPrim& pr = m->prims[p];
+        if (pr.parts_no >= m->parts_disp.size() || !m->parts_disp[pr.parts_no]) continue;  // src/model.rs:318-320
+        for (uint32_t start = 0; start < pr.index_num; start += MTR_CHUNK_NEW) {
+            DChunk c;
+            c.prim = (uint32_t)p;
+            c.start = start;
+            c.q_before = start >= 3 ? m->run[pr.index_ofs + start - 3] : 0;
+            // the run must not reach back before this primitive's first index
+            if (start >= 3 && c.q_before > start - 2) c.q_before = start - 2;
+            uint32_t nt = 0, end = std::min(pr.index_num, start + MTR_CHUNK_NEW);
+            for (uint32_t q = start; q < end; q++) {
+                if (pr.topology == 4) {
+                    uint32_t r = std::min(m->run[pr.index_ofs + q], q + 1);
+                    nt += r >= 3;
+                } else {
+                    nt += (q % 3 == 2);
+                }
+            }
+            c.ntris = nt;
+            m->ntris_visible += nt;
+            m->chunks.push_back(c);
+        }
+    }
+    m->chunks_dirty = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mtr_abi_version(void) { return MTR_ABI_VERSION; }
+
+const char* mtr_last_error(const mtr_device* dev) { return dev ? dev->err.c_str() : g_create_error.c_str(); }
+
+int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_device** out) {
+    if (!out) return fail(nullptr, MTR_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, MTR_E_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (hip_device < 0 || hip_device >= n) return fail(nullptr, MTR_E_INVALID, "hip_device out of range");
+    auto d = std::make_unique<mtr_device>();
+    d->hip_dev = hip_device;
+    HIPCHK(nullptr, hipSetDevice(hip_device));
+    if (hip_stream) {
+        d->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        HIPCHK(nullptr, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        d->own_stream = true;
+    }
+    *out = d.release();
+    return MTR_OK;
+}
+
+int32_t mtr_device_create(int32_t hip_device, mtr_device** out) {
+    return mtr_device_create_on_stream(hip_device, nullptr, out);
+}
+
+void mtr_device_destroy(mtr_device* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->hip_dev);
+    (void)hipStreamSynchronize(d->stream);
+    if (d->cube) mtr_model_destroy(d->cube);
+    for (auto& f : d->free_fb) {
+        (void)hipFree(f.color);
+        (void)hipFree(f.depth);
+        (void)hipFree(f.counters);
+    }
+    void* ptrs[] = {d->rec_hdr, d->rec_a, d->rec_b, d->chunk_info, d->bin_count, d->bin_fill,
+                    d->bin_start, d->seg_start, d->entries, d->segs, d->mats};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int32_t mtr_device_set_profiling(mtr_device* d, int32_t enable) {
+    if (!d) return MTR_E_INVALID;
+    d->profiling = enable != 0;
+    return MTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Texture::new
+// ---------------------------------------------------------------------------------------------
+int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, const void* data, size_t len,
+                           mtr_texture** out) {
+    if (!d || !out) return MTR_E_INVALID;
+    *out = nullptr;
+    if (!data || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad texture size/data");
+    if (fmt != MTR_TEX_RGBA8 && fmt != MTR_TEX_BC1 && fmt != MTR_TEX_BC7 && fmt != MTR_TEX_BC7_ALT)
+        return fail(d, MTR_E_UNSUPPORTED, "unhandled texture format " + std::to_string(fmt));  // src/rtexture.rs:159
+    const size_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+    const size_t need = fmt == MTR_TEX_RGBA8 ? (size_t)w * h * 4 : bw * bh * (fmt == MTR_TEX_BC1 ? 8 : 16);
+    if (len < need) return fail(d, MTR_E_INVALID, "texture data too short");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    auto t = std::make_unique<mtr_texture>();
+    t->dev = d; t->w = w; t->h = h; t->fmt = fmt; t->d_rgba = nullptr;
+    rc = dev_alloc(d, &t->d_rgba, (size_t)w * h * 4);
+    if (rc) return rc;
+    if (fmt == MTR_TEX_RGBA8) {
+        HIPCHK(d, hipMemcpyAsync(t->d_rgba, data, need, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+    } else {
+        uint8_t* d_blocks = nullptr;
+        rc = dev_alloc(d, &d_blocks, need);
+        if (rc) { (void)hipFree(t->d_rgba); return rc; }
+        HIPCHK(d, hipMemcpyAsync(d_blocks, data, need, hipMemcpyHostToDevice, d->stream));
+        if (fmt == MTR_TEX_BC1) mtr_launch_bc1_decode(d_blocks, t->d_rgba, w, h, d->stream);
+        else mtr_launch_bc7_decode(d_blocks, t->d_rgba, w, h, d->stream);
+        HIPCHK(d, hipGetLastError());
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        (void)hipFree(d_blocks);
+    }
+    *out = t.release();
+    return MTR_OK;
+}
+
+void mtr_texture_destroy(mtr_texture* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->dev->hip_dev);
+    (void)hipStreamSynchronize(t->dev->stream);
+    (void)hipFree(t->d_rgba);
+    delete t;
+}
+
+int32_t mtr_texture_read_rgba8(mtr_texture* t, void* out, size_t len) {
+    if (!t || !out) return MTR_E_INVALID;
+    mtr_device* d = t->dev;
+    if (len < (size_t)t->w * t->h * 4) return fail(d, MTR_E_INVALID, "output too small");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    HIPCHK(d, hipMemcpyAsync(out, t->d_rgba, (size_t)t->w * t->h * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    return MTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Model::new
+// ---------------------------------------------------------------------------------------------
+int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_len, const uint16_t* index_buf,
+                         size_t index_num, const mtr_primitive* prims, size_t nprims, const mtr_layout* layouts,
+                         const int32_t* prim_to_texture, mtr_texture* const* textures, size_t ntextures,
+                         const uint32_t* prim_debug_id, mtr_model** out) {
+    if (!d || !out) return MTR_E_INVALID;
+    *out = nullptr;
+    if (!vertex_buf || !index_buf || !prims || !layouts || nprims == 0 || nprims > 0xFFFF)
+        return fail(d, MTR_E_INVALID, "null or empty model input");
+    if (index_num > 0x7FFFFFFFu || vertex_len > 0xFFFFFFFFu) return fail(d, MTR_E_INVALID, "model too large");
+    auto m = std::make_unique<mtr_model>();
+    m->dev = d;
+    m->vertex_len = vertex_len;
+    m->prims.resize(nprims);
+    m->prim_to_texture.assign(nprims, -1);
+    m->debug_rgba8.resize(nprims);
+    for (size_t t = 0; t < ntextures; t++) {
+        if (!textures || !textures[t] || textures[t]->dev != d) return fail(d, MTR_E_INVALID, "bad texture handle");
+        m->textures.push_back(textures[t]);
+    }
+    for (size_t p = 0; p < nprims; p++) {
+        const uint32_t* w = prims[p].w;  // bit-fields: src/rmodel.rs:173-225
+        DPrim& pr = m->prims[p];
+        memset(&pr, 0, sizeof pr);
+        pr.vertex_num = (w[0] >> 16) & 0xffff;
+        pr.parts_no = w[1] & 0xfff;
+        pr.stride = (w[2] >> 16) & 0xff;
+        pr.topology = (w[2] >> 24) & 0x3f;
+        pr.vertex_base = w[4];
+        pr.index_ofs = w[6];
+        pr.index_num = w[7];
+        pr.index_base = w[8];
+        if (pr.topology != 4 && pr.topology != 3)  // PrimitiveTopology::from_repr().unwrap(), src/rmodel.rs:215
+            return fail(d, MTR_E_UNSUPPORTED, "primitive " + std::to_string(p) + ": topology " + std::to_string(pr.topology));
+        const mtr_layout& l = layouts[p];
+        if (l.num_elements > 8) return fail(d, MTR_E_INVALID, "layout has more than 8 elements");
+        bool has_pos = false, has_joint = false, has_weight = false;
+        uint32_t align_or = pr.vertex_base | pr.stride;
+        for (uint32_t i = 0; i < l.num_elements; i++) {
+            const mtr_element& e = l.elements[i];
+            if (e.format == MTR_IEF_SCMP3N) continue;  // src/rshader2.rs:509-512
+            if (e.semantic == MTR_SEM_POSITION || e.semantic == MTR_SEM_TEXCOORD) {
+                uint32_t nb = elem_bytes(e.format, e.count);
+                if (nb == 0)  // todo!() arms of src/rshader2.rs:516-564 and integer formats
+                    return fail(d, MTR_E_UNSUPPORTED, "primitive " + std::to_string(p) + ": unhandled element format " +
+                                                         std::to_string(e.format) + " x" + std::to_string(e.count));
+                if ((uint32_t)e.offset + nb > pr.stride) return fail(d, MTR_E_INVALID, "element outside the vertex stride");
+                align_or |= e.offset;
+                if (e.semantic == MTR_SEM_POSITION) {
+                    has_pos = true; pr.pos_fmt = e.format; pr.pos_cnt = e.count; pr.pos_off = e.offset;
+                } else {
+                    pr.has_uv = 1; pr.uv_fmt = e.format; pr.uv_cnt = e.count; pr.uv_off = e.offset;
+                }
+            } else if (e.semantic == MTR_SEM_JOINT) {
+                if (e.format != MTR_IEF_U8 || e.count != 4) return fail(d, MTR_E_UNSUPPORTED, "Joint must be U8 x4");
+                if ((uint32_t)e.offset + 4 > pr.stride) return fail(d, MTR_E_INVALID, "element outside the vertex stride");
+                has_joint = true; pr.joint_off = e.offset; align_or |= e.offset;
+            } else if (e.semantic == MTR_SEM_WEIGHT) {
+                if (e.format != MTR_IEF_U8N || e.count != 4) return fail(d, MTR_E_UNSUPPORTED, "Weight must be U8N x4");
+                if ((uint32_t)e.offset + 4 > pr.stride) return fail(d, MTR_E_INVALID, "element outside the vertex stride");
+                has_weight = true; pr.weight_off = e.offset; align_or |= e.offset;
+            }  // other names: `_ => continue`, src/rshader2.rs:506
+        }
+        if (!has_pos) return fail(d, MTR_E_UNSUPPORTED, "primitive " + std::to_string(p) + ": no Position element");
+        pr.skinnable = has_joint && has_weight;
+        pr.aligned4 = (align_or & 3) == 0;
+        if ((size_t)pr.vertex_base + (size_t)pr.vertex_num * pr.stride > vertex_len)
+            return fail(d, MTR_E_INVALID, "primitive " + std::to_string(p) + ": vertex slice outside the buffer");
+        if ((size_t)pr.index_ofs + pr.index_num > index_num)
+            return fail(d, MTR_E_INVALID, "primitive " + std::to_string(p) + ": index range outside the buffer");
+        int32_t tex = prim_to_texture ? prim_to_texture[p] : -1;
+        if (tex >= (int32_t)ntextures) return fail(d, MTR_E_INVALID, "prim_to_texture out of range");
+        m->prim_to_texture[p] = tex < 0 ? -1 : tex;
+        uint32_t id = prim_debug_id ? prim_debug_id[p] : 0;
+        float c[4];
+        for (int k = 0; k < 3; k++) c[k] = (float)kDebugPalette[id % 20][k] / 255.0f;  // debug_ids.wgsl:46
+        c[3] = 1.0f;
+        m->debug_rgba8[p] = pack_rgba8(c);
+    }
+    m->parts_disp.assign(nprims, 1);  // src/model.rs:270
+    m->indices.assign(index_buf, index_buf + index_num);
+    m->run.resize(index_num);
+    {
+        // runs restart at every primitive's first index so a chunk never looks outside its primitive
+        std::vector<uint8_t> is_first(index_num + 1, 0);
+        for (auto& pr : m->prims) is_first[pr.index_ofs] = 1;
+        uint32_t r = 0;
+        for (size_t i = 0; i < index_num; i++) {
+            if (is_first[i]) r = 0;
+            r = index_buf[i] == 0xFFFF ? 0 : r + 1;
+            m->run[i] = r;
+        }
+    }
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    if ((rc = dev_alloc(d, &m->d_vbuf, vertex_len + 16))) return rc;
+    if ((rc = dev_alloc(d, &m->d_ibuf, index_num + 2))) return rc;
+    if ((rc = dev_alloc(d, &m->d_prims, nprims))) return rc;
+    HIPCHK(d, hipMemcpyAsync(m->d_vbuf, vertex_buf, vertex_len, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(d, hipMemcpyAsync(m->d_ibuf, index_buf, index_num * 2, hipMemcpyHostToDevice, d->stream));
+    HIPCHK(d, hipMemcpyAsync(m->d_prims, m->prims.data(), nprims * sizeof(DPrim), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    *out = m.release();
+    return MTR_OK;
+}
+
+void mtr_model_destroy(mtr_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->dev->hip_dev);
+    (void)hipStreamSynchronize(m->dev->stream);
+    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks, m->d_palette};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete m;
+}
+
+int32_t mtr_model_set_parts_disp(mtr_model* m, const uint8_t* parts_disp, size_t n) {
+    if (!m || (!parts_disp && n)) return MTR_E_INVALID;
+    m->parts_disp.assign(parts_disp, parts_disp + n);
+    m->chunks_dirty = true;
+    return MTR_OK;
+}
+
+int32_t mtr_model_set_palette(mtr_model* m, const float* mats, size_t n) {
+    if (!m) return MTR_E_INVALID;
+    mtr_device* d = m->dev;
+    if (n > 256 || (!mats && n)) return fail(d, MTR_E_INVALID, "palette: at most 256 matrices (u8 joint indices)");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    if (m->d_palette) { (void)hipFree(m->d_palette); m->d_palette = nullptr; }
+    m->npal = (uint32_t)n;
+    if (n) {
+        if ((rc = dev_alloc(d, &m->d_palette, n * 16))) return rc;
+        HIPCHK(d, hipMemcpyAsync(m->d_palette, mats, n * 64, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+    }
+    return MTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// instance batches
+// ---------------------------------------------------------------------------------------------
+int32_t mtr_batch_create(mtr_device* d, mtr_model* model, size_t n, const float* model_mats, const float* palettes,
+                         size_t npal, const int32_t* texture_override, mtr_batch** out) {
+    if (!d || !out) return MTR_E_INVALID;
+    *out = nullptr;
+    if (!model || model->dev != d || !model_mats || n == 0 || n > 0xFFFFu)
+        return fail(d, MTR_E_INVALID, "bad batch arguments");
+    if (npal > 256 || (npal && !palettes)) return fail(d, MTR_E_INVALID, "palette: at most 256 matrices");
+    auto b = std::make_unique<mtr_batch>();
+    b->dev = d; b->model = model; b->n = (uint32_t)n; b->npal = palettes ? (uint32_t)npal : 0;
+    if (texture_override) {
+        b->tex_override.assign(texture_override, texture_override + n);
+        for (int32_t t : b->tex_override)
+            if (t >= (int32_t)model->textures.size()) return fail(d, MTR_E_INVALID, "texture_override out of range");
+    }
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    if ((rc = dev_alloc(d, &b->d_model_mats, n * 16))) return rc;
+    HIPCHK(d, hipMemcpyAsync(b->d_model_mats, model_mats, n * 64, hipMemcpyHostToDevice, d->stream));
+    if (b->npal) {
+        if ((rc = dev_alloc(d, &b->d_palettes, n * npal * 16))) return rc;
+        HIPCHK(d, hipMemcpyAsync(b->d_palettes, palettes, n * npal * 64, hipMemcpyHostToDevice, d->stream));
+    }
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    *out = b.release();
+    return MTR_OK;
+}
+
+void mtr_batch_destroy(mtr_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->dev->hip_dev);
+    (void)hipStreamSynchronize(b->dev->stream);
+    if (b->d_model_mats) (void)hipFree(b->d_model_mats);
+    if (b->d_palettes) (void)hipFree(b->d_palettes);
+    delete b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame
+// ---------------------------------------------------------------------------------------------
+int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear_rgba[4], float clear_depth,
+                        mtr_frame** out) {
+    if (!d || !out) return MTR_E_INVALID;
+    *out = nullptr;
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || !clear_rgba) return fail(d, MTR_E_INVALID, "bad frame size");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    auto f = std::make_unique<mtr_frame>();
+    f->dev = d; f->w = w; f->h = h;
+    f->clear_rgba8 = pack_rgba8(clear_rgba);
+    f->clear_depth = clear_depth;
+    bool found = false;
+    for (size_t i = 0; i < d->free_fb.size(); i++)
+        if (d->free_fb[i].w == w && d->free_fb[i].h == h) {
+            f->fb = d->free_fb[i];
+            d->free_fb.erase(d->free_fb.begin() + (long)i);
+            found = true;
+            break;
+        }
+    if (!found) {
+        f->fb.w = w; f->fb.h = h;
+        if ((rc = dev_alloc(d, &f->fb.color, (size_t)w * h * 4))) return rc;
+        if ((rc = dev_alloc(d, &f->fb.depth, (size_t)w * h))) return rc;
+        if ((rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM))) return rc;
+    }
+    *out = f.release();
+    return MTR_OK;
+}
+
+void mtr_frame_destroy(mtr_frame* f) {
+    if (!f) return;
+    mtr_device* d = f->dev;
+    (void)hipSetDevice(d->hip_dev);
+    if (f->have_events)
+        for (auto& e : f->ev)
+            if (e) (void)hipEventDestroy(e);
+    // stream order protects the buffers: a later frame's kernels run after this frame's
+    d->free_fb.push_back(f->fb);
+    delete f;
+}
+
+int32_t mtr_frame_set_shard(mtr_frame* f, uint32_t rank, uint32_t world) {
+    if (!f) return MTR_E_INVALID;
+    if (world == 0 || rank >= world) return fail(f->dev, MTR_E_INVALID, "bad shard rank/world");
+    f->shard_rank = rank; f->shard_world = world;
+    return MTR_OK;
+}
+
+static int32_t check_model_for_draw(mtr_frame* f, mtr_model* m) {
+    mtr_device* d = f->dev;
+    if (!m || m->dev != d) return fail(d, MTR_E_INVALID, "model belongs to another device");
+    if (f->submitted) return fail(d, MTR_E_INVALID, "frame already submitted");
+    for (size_t p = 0; p < m->prims.size(); p++)
+        if (m->prims[p].parts_no >= m->parts_disp.size())  // self.parts_disp[parts_no] would panic, src/model.rs:318
+            return fail(d, MTR_E_INVALID, "primitive " + std::to_string(p) + ": parts_no outside parts_disp");
+    return MTR_OK;
+}
+
+int32_t mtr_frame_draw_model(mtr_frame* f, mtr_model* m, const float view_proj[16]) {
+    if (!f || !view_proj) return MTR_E_INVALID;
+    int32_t rc = check_model_for_draw(f, m);
+    if (rc) return rc;
+    Draw dr{};
+    dr.model = m; dr.d_model_mats = nullptr; dr.d_palettes = m->d_palette; dr.npal = m->npal;
+    dr.pal_stride = 0; dr.ninst = 1; dr.shader_override = -1; dr.blend = true;
+    memcpy(dr.vp, view_proj, sizeof dr.vp);
+    f->draws.push_back(std::move(dr));
+    return MTR_OK;
+}
+
+int32_t mtr_frame_draw_batch(mtr_frame* f, mtr_batch* b, const float view_proj[16]) {
+    if (!f || !b || !view_proj) return MTR_E_INVALID;
+    if (b->dev != f->dev) return fail(f->dev, MTR_E_INVALID, "batch belongs to another device");
+    int32_t rc = check_model_for_draw(f, b->model);
+    if (rc) return rc;
+    Draw dr{};
+    dr.model = b->model; dr.d_model_mats = b->d_model_mats;
+    dr.d_palettes = b->npal ? b->d_palettes : nullptr;
+    dr.npal = b->npal; dr.pal_stride = b->npal * 16; dr.ninst = b->n;
+    dr.tex_override = b->tex_override; dr.shader_override = -1; dr.blend = true;
+    memcpy(dr.vp, view_proj, sizeof dr.vp);
+    f->draws.push_back(std::move(dr));
+    return MTR_OK;
+}
+
+int32_t mtr_frame_draw_instances(mtr_frame* f, mtr_model* m, const float* model_mats, const float* palettes,
+                                 size_t npal, size_t n, const float view_proj[16]) {
+    if (!f || !view_proj) return MTR_E_INVALID;
+    mtr_batch* b = nullptr;
+    int32_t rc = mtr_batch_create(f->dev, m, n, model_mats, palettes, npal, nullptr, &b);
+    if (rc) return rc;
+    rc = mtr_frame_draw_batch(f, b, view_proj);
+    if (rc) { mtr_batch_destroy(b); return rc; }
+    f->draws.back().owned_batch.reset(b);
+    return MTR_OK;
+}
+
+int32_t mtr_frame_draw_overlay_cubes(mtr_frame* f, const float camera[16], const float* inst_mats, size_t n) {
+    if (!f || !camera || (!inst_mats && n)) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (n == 0) return MTR_OK;
+    if (!d->cube) {
+        // src/debug_overlay.rs:10-35
+        static const float verts[24] = {1, 1, -1, 1, -1, -1, 1, 1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1};
+        static const uint16_t idx[36] = {4, 2, 0, 2, 7, 3, 6, 5, 7, 1, 7, 5, 0, 3, 1, 4, 1, 5,
+                                         4, 6, 2, 2, 6, 7, 6, 4, 5, 1, 3, 7, 0, 2, 3, 4, 0, 1};
+        mtr_primitive pr{};
+        pr.w[0] = 8u << 16;
+        pr.w[2] = (12u << 16) | (3u << 24);
+        pr.w[7] = 36;
+        mtr_layout lay{};
+        lay.num_elements = 1;
+        lay.elements[0].semantic = MTR_SEM_POSITION;
+        lay.elements[0].format = MTR_IEF_F32;
+        lay.elements[0].count = 3;
+        int32_t rc = mtr_model_create(d, verts, sizeof verts, idx, 36, &pr, 1, &lay, nullptr, nullptr, 0, nullptr, &d->cube);
+        if (rc) return rc;
+    }
+    mtr_batch* b = nullptr;
+    int32_t rc = mtr_batch_create(d, d->cube, n, inst_mats, nullptr, 0, nullptr, &b);
+    if (rc) return rc;
+    rc = mtr_frame_draw_batch(f, b, camera);
+    if (rc) { mtr_batch_destroy(b); return rc; }
+    Draw& dr = f->draws.back();
+    dr.owned_batch.reset(b);
+    dr.shader_override = MTR_SH_CONST;
+    const float c[4] = {0.1f, 0.2f, 0.3f, 1.0f};  // src/shaders/debug_overlay.wgsl:30
+    dr.const_rgba8 = pack_rgba8(c);
+    dr.blend = false;  // blend: None, src/debug_overlay.rs:174
+    return MTR_OK;
+}
+
+static int32_t run_frame(mtr_frame* f) {
+    mtr_device* d = f->dev;
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    const uint32_t nbx = (f->w + MTR_BIN - 1) / MTR_BIN, nby = (f->h + MTR_BIN - 1) / MTR_BIN, nbins = nbx * nby;
+    // ---- chunk tables, capacities ----
+    uint64_t total_chunks = 0, nmats = 0, tris_in = 0;
+    for (auto& dr : f->draws) {
+        mtr_model* m = dr.model;
+        if (m->chunks_dirty) {
+            rebuild_chunks(m);
+            if (m->d_chunks) { HIPCHK(d, hipStreamSynchronize(d->stream)); (void)hipFree(m->d_chunks); m->d_chunks = nullptr; }
+            if ((rc = dev_alloc(d, &m->d_chunks, m->chunks.size()))) return rc;
+            HIPCHK(d, hipMemcpyAsync(m->d_chunks, m->chunks.data(), m->chunks.size() * sizeof(DChunk), hipMemcpyHostToDevice, d->stream));
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+        }
+        total_chunks += (uint64_t)m->chunks.size() * dr.ninst;
+        nmats += (uint64_t)m->prims.size() * (dr.tex_override.empty() ? 1 : dr.ninst);
+        tris_in += m->ntris_visible * dr.ninst;
+    }
+    if (total_chunks > 0x3FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
+    const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
+    if (rec_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many triangles in one frame");
+    if (rec_need > d->rec_cap || !d->rec_a) {
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        uint32_t c0 = d->rec_cap, c1 = d->rec_cap, c2 = d->rec_cap;
+        if ((rc = dev_grow(d, &d->rec_hdr, &c0, rec_need))) return rc;
+        if ((rc = dev_grow(d, &d->rec_a, &c1, rec_need))) return rc;
+        if ((rc = dev_grow(d, &d->rec_b, &c2, rec_need))) return rc;
+        d->rec_cap = c0;
+    }
+    if (total_chunks > d->chunk_cap || !d->chunk_info) {
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        if ((rc = dev_grow(d, &d->chunk_info, &d->chunk_cap, total_chunks))) return rc;
+    }
+    if (nbins + 1 > d->bin_cap || !d->bin_count) {
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        uint32_t c0 = d->bin_cap, c1 = d->bin_cap, c2 = d->bin_cap, c3 = d->bin_cap;
+        if ((rc = dev_grow(d, &d->bin_count, &c0, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &d->bin_fill, &c1, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &d->bin_start, &c2, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &d->seg_start, &c3, nbins + 1))) return rc;
+        d->bin_cap = c0;
+    }
+    {
+        const uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2), s_need = std::max<uint64_t>(1u << 18, total_chunks * 8);
+        if (e_need > d->entry_cap || !d->entries) {
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+            if ((rc = dev_grow(d, &d->entries, &d->entry_cap, std::min<uint64_t>(e_need, 0xFFFFFFF0ull)))) return rc;
+        }
+        if (s_need > d->seg_cap || !d->segs) {
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+            if ((rc = dev_grow(d, &d->segs, &d->seg_cap, std::min<uint64_t>(s_need, 0xFFFFFFF0ull)))) return rc;
+        }
+    }
+    // ---- material table ----
+    std::vector<DMat>& mats = f->mats_host;
+    mats.clear();
+    mats.reserve(nmats);
+    std::vector<uint32_t> mat_base(f->draws.size()), mat_stride(f->draws.size());
+    for (size_t di = 0; di < f->draws.size(); di++) {
+        Draw& dr = f->draws[di];
+        mtr_model* m = dr.model;
+        mat_base[di] = (uint32_t)mats.size();
+        mat_stride[di] = dr.tex_override.empty() ? 0 : (uint32_t)m->prims.size();
+        const uint32_t reps = dr.tex_override.empty() ? 1 : dr.ninst;
+        for (uint32_t r = 0; r < reps; r++)
+            for (size_t p = 0; p < m->prims.size(); p++) {
+                DMat dm{};
+                int32_t tex = m->prim_to_texture[p];
+                if (tex >= 0 && !dr.tex_override.empty() && dr.tex_override[r] >= 0) tex = dr.tex_override[r];
+                dm.blend = dr.blend ? 1 : 0;
+                if (dr.shader_override == MTR_SH_CONST) {
+                    dm.shader = MTR_SH_CONST; dm.rgba8 = dr.const_rgba8;
+                } else if (tex >= 0 && m->prims[p].has_uv) {  // src/model.rs:212-216
+                    dm.shader = MTR_SH_TEXTURED;
+                    dm.tex = m->textures[(size_t)tex]->d_rgba; dm.tw = m->textures[(size_t)tex]->w; dm.th = m->textures[(size_t)tex]->h;
+                } else {
+                    dm.shader = MTR_SH_DEBUG; dm.rgba8 = m->debug_rgba8[p];
+                }
+                mats.push_back(dm);
+            }
+    }
+    if (mats.size() > d->mat_cap || !d->mats) {
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        if ((rc = dev_grow(d, &d->mats, &d->mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
+    }
+    // the material table is tiny; the copy is ordered on the stream before the kernels that read it
+    HIPCHK(d, hipMemcpyAsync(d->mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->stream));
+
+    FrameBuffers fb{};
+    fb.rec_hdr = d->rec_hdr; fb.rec_a = d->rec_a; fb.rec_b = d->rec_b; fb.chunk_info = d->chunk_info;
+    fb.bin_count = d->bin_count; fb.bin_fill = d->bin_fill; fb.bin_start = d->bin_start; fb.seg_start = d->seg_start;
+    fb.entries = d->entries; fb.segs = d->segs; fb.counters = f->fb.counters;
+    fb.rec_cap = d->rec_cap; fb.entry_cap = d->entry_cap; fb.seg_cap = d->seg_cap;
+    fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
+    fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
+
+    if (d->profiling && !f->have_events) {
+        for (auto& e : f->ev) HIPCHK(d, hipEventCreate(&e));
+        f->have_events = true;
+    }
+    const bool prof = d->profiling && f->have_events;
+    HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), d->stream));
+    HIPCHK(d, hipMemsetAsync(d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[0], d->stream));
+    uint32_t chunk_base = 0;
+    for (size_t di = 0; di < f->draws.size(); di++) {
+        Draw& dr = f->draws[di];
+        mtr_model* m = dr.model;
+        GeomParams gp{};
+        gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = m->d_chunks;
+        gp.nchunks = (uint32_t)m->chunks.size(); gp.ninst = dr.ninst;
+        gp.model_mats = dr.d_model_mats; gp.palettes = dr.d_palettes; gp.npal = dr.d_palettes ? dr.npal : 0;
+        gp.pal_stride = dr.pal_stride;
+        memcpy(gp.vp, dr.vp, sizeof gp.vp);
+        gp.chunk_base = chunk_base; gp.mat_base = mat_base[di]; gp.mat_inst_stride = mat_stride[di];
+        gp.fb = fb;
+        mtr_launch_geom(gp, d->stream);
+        chunk_base += gp.nchunks * dr.ninst;
+    }
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[1], d->stream));
+    mtr_launch_scan(fb, d->stream);
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[2], d->stream));
+    mtr_launch_fill(fb, (uint32_t)total_chunks, d->stream);
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[3], d->stream));
+    TileParams tp{};
+    tp.fb = fb; tp.mats = d->mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
+    tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
+    mtr_launch_tile(tp, d->stream);
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[4], d->stream));
+    HIPCHK(d, hipGetLastError());
+    f->stats = mtr_frame_stats{};
+    f->stats.tris_in = tris_in;
+    f->stats.width = f->w; f->stats.height = f->h; f->stats.nbins = nbins; f->stats.ndraws = (uint32_t)f->draws.size();
+    return MTR_OK;
+}
+
+int32_t mtr_frame_submit(mtr_frame* f) {
+    if (!f) return MTR_E_INVALID;
+    if (f->submitted) return fail(f->dev, MTR_E_INVALID, "frame already submitted");
+    int32_t rc = run_frame(f);
+    if (rc) return rc;
+    f->submitted = true;
+    return MTR_OK;
+}
+
+int32_t mtr_frame_wait(mtr_frame* f) {
+    if (!f) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (!f->submitted) return fail(d, MTR_E_INVALID, "frame not submitted");
+    if (f->waited) return MTR_OK;
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        uint32_t ctr[CTR_NUM];
+        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        f->stats.tris_setup = ctr[CTR_RECORDS];
+        f->stats.bin_entries = ctr[CTR_ENTRIES];
+        f->stats.segments = ctr[CTR_SEGS];
+        if (!ctr[CTR_OVERFLOW]) {
+            if (d->profiling && f->have_events)
+                for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
+            f->waited = true;
+            return MTR_OK;
+        }
+        if (ctr[CTR_OVERFLOW] & 1u) return fail(d, MTR_E_OVERFLOW, "record capacity exceeded (internal bound violated)");
+        // bin queues too small: grow to what the scan measured and run the frame again
+        const uint64_t e_need = (uint64_t)ctr[CTR_ENTRIES] + ctr[CTR_ENTRIES] / 4 + 1024;
+        const uint64_t s_need = (uint64_t)ctr[CTR_SEGS] + ctr[CTR_SEGS] / 4 + 1024;
+        if (e_need > 0xFFFFFFF0ull || s_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "bin queues exceed 2^32 entries");
+        if (e_need > d->entry_cap && (rc = dev_grow(d, &d->entries, &d->entry_cap, e_need))) return rc;
+        if (s_need > d->seg_cap && (rc = dev_grow(d, &d->segs, &d->seg_cap, s_need))) return rc;
+        if ((rc = run_frame(f))) return rc;
+    }
+    return fail(d, MTR_E_OVERFLOW, "bin queues still overflow after growing");
+}
+
+int32_t mtr_frame_end(mtr_frame* f) {
+    int32_t rc = mtr_frame_submit(f);
+    if (rc) return rc;
+    return mtr_frame_wait(f);
+}
+
+int32_t mtr_frame_read_color(mtr_frame* f, void* rgba8, size_t len) {
+    if (!f || !rgba8) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (len < (size_t)f->w * f->h * 4) return fail(d, MTR_E_INVALID, "output too small");
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    HIPCHK(d, hipMemcpyAsync(rgba8, f->fb.color, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    return MTR_OK;
+}
+
+int32_t mtr_frame_read_depth(mtr_frame* f, float* depth, size_t count) {
+    if (!f || !depth) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (count < (size_t)f->w * f->h) return fail(d, MTR_E_INVALID, "output too small");
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    HIPCHK(d, hipMemcpyAsync(depth, f->fb.depth, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    return MTR_OK;
+}
+
+void* mtr_frame_color_devptr(mtr_frame* f) { return f ? f->fb.color : nullptr; }
+void* mtr_frame_depth_devptr(mtr_frame* f) { return f ? f->fb.depth : nullptr; }
+
+int32_t mtr_frame_get_stats(mtr_frame* f, mtr_frame_stats* out) {
+    if (!f || !out) return MTR_E_INVALID;
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    *out = f->stats;
+    return MTR_OK;
+}
+
+int32_t mtr_frame_get_timings(mtr_frame* f, float ms[MTR_STAGE_COUNT]) {
+    if (!f || !ms) return MTR_E_INVALID;
+    if (!f->have_events) return fail(f->dev, MTR_E_INVALID, "profiling was not enabled for this frame");
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    memcpy(ms, f->ms, sizeof f->ms);
+    return MTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-test hooks
+// ---------------------------------------------------------------------------------------------
+int32_t mtr_model_vertex_stage(mtr_model* m, size_t prim, const float M[16], float* out_clip, float* out_uv) {
+    if (!m || !M || !out_clip || !out_uv) return MTR_E_INVALID;
+    mtr_device* d = m->dev;
+    if (prim >= m->prims.size()) return fail(d, MTR_E_INVALID, "primitive out of range");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    const uint32_t nv = m->prims[prim].vertex_num;
+    if (nv == 0) return MTR_OK;
+    float *d_clip = nullptr, *d_uv = nullptr;
+    if ((rc = dev_alloc(d, &d_clip, (size_t)nv * 4))) return rc;
+    if ((rc = dev_alloc(d, &d_uv, (size_t)nv * 2))) return rc;
+    GeomParams gp{};
+    gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.ninst = 1;
+    gp.palettes = m->d_palette; gp.npal = m->d_palette ? m->npal : 0;
+    memcpy(gp.vp, M, sizeof gp.vp);
+    mtr_launch_vertex_stage(gp, (uint32_t)prim, d_clip, d_uv, d->stream);
+    HIPCHK(d, hipGetLastError());
+    HIPCHK(d, hipMemcpyAsync(out_clip, d_clip, (size_t)nv * 16, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipMemcpyAsync(out_uv, d_uv, (size_t)nv * 8, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    (void)hipFree(d_clip);
+    (void)hipFree(d_uv);
+    return MTR_OK;
+}
+
+uint32_t mtr_crc32(const uint8_t* bytes, size_t len, uint32_t init) {
+    // src/util/crc.rs:36-50: reflected 0xEDB88320 table, no final xor, stops at the first NUL
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+            table[i] = c;
+        }
+        ready = true;
+    }
+    uint32_t v = init;
+    for (size_t i = 0; i < len && bytes[i] != 0; i++) v = table[(bytes[i] ^ v) & 0xff] ^ (v >> 8);
+    return v;
+}
+
+}  // extern "C"

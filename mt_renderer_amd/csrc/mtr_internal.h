@@ -1,0 +1,132 @@
+// mtr_internal.h -- device-visible data layout of the rModel draw path (gfx950).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   model   : raw vertex bytes, u16 indices, DPrim[nprims], DChunk[nchunks]   (resident, static)
+//   frame   : RecHdr/RecA/RecB[record capacity]  one record per surviving screen triangle, written
+//             as one contiguous, submission-ordered run per geometry wave ("chunk run");
+//             ChunkInfo[total chunks] = {run base, run length};
+//             bin_count/bin_fill[nbins] (u64: lo = entries, hi = segments), bin_start/seg_start;
+//             entries[] (record ids, grouped by bin, ordered inside a segment),
+//             segs[]    ({order key, offset, count} runs, grouped by bin, sorted by the tile kernel)
+//             colour RGBA8 [H][W], depth f32 [H][W].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MTR_BIN 32             // screen bin edge in pixels (one workgroup of the tile kernel)
+#define MTR_BIN_SHIFT 5
+#define MTR_SUB 8              // sub-tile edge: one wave64 = one 8x8 pixel block
+#define MTR_CHUNK_NEW 62       // strip positions that complete a triangle per geometry wave
+#define MTR_CHUNK_SLOTS 124    // worst case records per chunk (near clip: 2 per position)
+#define MTR_GUARD_BAND 1048576.0f
+#define MTR_SEG_CAP 2048       // segments sorted in LDS per pass by the tile kernel
+#define MTR_TILE_CHUNK 256     // triangles set up per tile-kernel pass
+
+enum { MTR_SH_DEBUG = 0, MTR_SH_TEXTURED = 1, MTR_SH_CONST = 2 };
+
+struct DPrim {
+    uint32_t vertex_base, vertex_num, stride;
+    uint32_t index_ofs, index_num, index_base;
+    uint32_t topology;  // 4 strip, 3 list
+    uint32_t pos_fmt, pos_cnt, pos_off;
+    uint32_t uv_fmt, uv_cnt, uv_off, has_uv;
+    uint32_t joint_off, weight_off, skinnable;
+    uint32_t aligned4;  // vertex_base, stride and every bound offset are multiples of 4
+    uint32_t parts_no;
+    uint32_t pad;
+};
+
+struct DChunk {
+    uint32_t prim;      // primitive index
+    uint32_t start;     // first strip position whose triangle this chunk owns
+    uint32_t q_before;  // strip: consecutive non-restart indices right before position start-2
+    uint32_t ntris;     // input triangles completed inside this chunk (statistics)
+};
+
+struct DMat {            // one per (draw, [instance,] primitive)
+    uint32_t shader;     // MTR_SH_*
+    uint32_t rgba8;      // SH_DEBUG / SH_CONST: the quantised source colour
+    uint32_t blend;      // alpha blending on (src/model.rs:243-246) / off (debug overlay)
+    uint32_t tw, th;     // texture size
+    uint32_t pad;
+    const uint8_t* tex;  // decoded RGBA8 texels
+};
+
+struct RecHdr {          // 8 B: bins covered, inclusive
+    uint16_t bx0, by0, bx1, by1;
+};
+struct RecA {            // 48 B: what coverage + depth need
+    int32_t X0, Y0, X1, Y1;
+    int32_t X2, Y2;
+    float z0, z1;
+    float z2;
+    uint32_t mat;
+    uint32_t pad0, pad1;
+};
+struct RecB {            // 48 B: perspective-correct texcoords (textured primitives only)
+    float iw0, iw1, iw2, up0;
+    float up1, up2, vp0, vp1;
+    float vp2, pad0, pad1, pad2;
+};
+struct ChunkInfo {
+    uint32_t base, n;
+};
+struct Seg {             // 16 B
+    uint32_t key;        // global chunk id * 2 + round: submission order of the run
+    uint32_t off;        // offset inside the bin's entry range
+    uint32_t cnt;
+    uint32_t pad;
+};
+
+enum { CTR_RECORDS = 0, CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_NUM = 8 };
+
+struct FrameBuffers {
+    RecHdr* rec_hdr;
+    RecA* rec_a;
+    RecB* rec_b;
+    ChunkInfo* chunk_info;
+    unsigned long long* bin_count;  // lo32 entries, hi32 segments
+    unsigned long long* bin_fill;
+    uint32_t* bin_start;            // nbins + 1
+    uint32_t* seg_start;            // nbins + 1
+    uint32_t* entries;
+    Seg* segs;
+    uint32_t* counters;             // CTR_*
+    uint32_t rec_cap, entry_cap, seg_cap;
+    uint32_t W, H, nbx, nby;
+    uint32_t shard_rank, shard_world;
+};
+
+struct GeomParams {
+    const uint8_t* vbuf;
+    const uint16_t* ibuf;
+    const DPrim* prims;
+    const DChunk* chunks;
+    uint32_t nchunks;
+    uint32_t ninst;
+    const float* model_mats;  // ninst*16 or nullptr
+    const float* palettes;    // per instance npal*16 floats (stride pal_stride floats) or nullptr
+    uint32_t npal, pal_stride;
+    float vp[16];
+    uint32_t chunk_base;      // global chunk id of (instance 0, chunk 0)
+    uint32_t mat_base, mat_inst_stride;
+    FrameBuffers fb;
+};
+
+struct TileParams {
+    FrameBuffers fb;
+    const DMat* mats;
+    uint8_t* color;  // RGBA8
+    float* depth;
+    uint32_t clear_rgba8;
+    float clear_depth;
+};
+
+// launchers (defined in the .hip files, called from mtr_api.cpp)
+void mtr_launch_geom(const GeomParams& p, hipStream_t s);
+void mtr_launch_scan(const FrameBuffers& fb, hipStream_t s);
+void mtr_launch_fill(const FrameBuffers& fb, uint32_t total_chunks, hipStream_t s);
+void mtr_launch_tile(const TileParams& p, hipStream_t s);
+void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s);
+void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
+void mtr_launch_bc7_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);

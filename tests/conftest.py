@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    """One mtr Device for the whole GPU session (the HIP library must load: no CPU fallback)."""
+    from mt_renderer_amd import api
+    dev = api.Device(0)
+    yield dev
+    dev.close()

@@ -1,0 +1,68 @@
+"""Shared helpers of the parity tests: render one scene description through the oracle and through
+libmtr.so and compare bit for bit."""
+from __future__ import annotations
+
+import numpy as np
+
+from mt_renderer_amd import scene
+from oracle import oracle as orc
+
+
+def render_oracle(w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, nthreads=1):
+    """draws: list of dicts {md, M | (vp, model_mats, palettes, tex_override), palette}"""
+    f = orc.OracleFrame(w, h, clear, clear_depth)
+    cache = {}
+    for d in draws:
+        md = d["md"]
+        om = cache.setdefault(id(md), orc.OracleModel(md))
+        if "overlay" in d:
+            f.draw_overlay_cubes(d["vp"], d["overlay"])
+        elif "model_mats" in d:
+            f.draw_instances(om, d["vp"], d["model_mats"], d.get("palettes"), d.get("tex_override"), nthreads)
+        else:
+            f.draw(om, d["M"], d.get("palette"), nthreads=nthreads)
+    out = f.color(), f.depth(), f.stats()
+    f.close()
+    return out
+
+
+def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, shard=None):
+    from mt_renderer_amd import api
+    fr = api.Frame(dev, w, h, clear, clear_depth)
+    if shard:
+        fr.set_shard(*shard)
+    models, batches = {}, []
+    try:
+        for d in draws:
+            md = d["md"]
+            if "overlay" in d:
+                fr.draw_overlay_cubes(d["vp"], d["overlay"])
+                continue
+            if id(md) not in models:
+                models[id(md)] = api.Model.new(dev, md)
+            m = models[id(md)]
+            if "model_mats" in d:
+                b = api.Batch(dev, m, d["model_mats"], d.get("palettes"), d.get("tex_override"))
+                batches.append(b)
+                fr.draw_batch(b, d["vp"])
+            else:
+                m.set_palette(d.get("palette"))
+                m.render(fr, d["M"])
+        fr.end()
+        return fr.color(), fr.depth(), fr.stats()
+    finally:
+        fr.close()
+        for b in batches:
+            b.close()
+        for m in models.values():
+            m.close()
+
+
+def assert_same(gpu, ref, what=""):
+    gc, gd, gs = gpu
+    rc, rd, rs = ref
+    nd = int((gd.view(np.uint32) != rd.view(np.uint32)).sum())
+    ncol = int((gc != rc).any(axis=-1).sum())
+    assert gs["tris_in"] == rs["tris_in"], (what, gs, rs)
+    assert gs["tris_setup"] == rs["tris_setup"], (what, gs, rs)
+    assert nd == 0 and ncol == 0, f"{what}: {nd} depth pixels and {ncol} colour pixels differ"
