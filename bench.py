@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- the rModel draw path on MI355X: Mtris/s + ms/frame on the headline scene
+(1 000 000 triangles, 64 bones, 1920x1080; BASELINE.json `metric`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one frame: clear (fused) -> geometry -> bin -> tile raster/shade -> framebuffer complete in
+HBM (N > 1: after the RCCL all-gather of the colour shards).  All inputs (vertex/index buffers, bone
+palette, transforms) are resident in HBM before the timed region.  One process per GPU; N > 1 shards
+the 32x32-pixel bins over the ranks (bin % N == rank) and exchanges colour with one all-gather.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HBM-bound accounting, hipEvent
+timing on the library's own stream) and `cpu_baseline` (the CPU oracle -- kind "port": the
+reference has no CPU path at all -- on a bounded sample of the same workload, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(md, width, height, npalettes, nbones=64):
+    """B = V*stride + I*2 + W*H*(4+4) + N_pal*J*64 (+ T_unique, 0 for the debug-id shader)."""
+    from mt_renderer_amd.scene import unpack_primitive
+    v = i = 0
+    for p in range(md.nprims):
+        f = unpack_primitive(md.prims[p])
+        v += f["vertex_num"] * f["vertex_stride"]
+        i += f["index_num"] * 2
+    return v + i + width * height * 8 + npalettes * nbones * 64
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from mt_renderer_amd import api, scene
+
+    W, H = args.width, args.height
+    md = scene.headline_model()
+    ntris = md.input_triangles()
+    palette = scene.bone_palette()
+    M = scene.to_f32_colmajor(scene.headline_transform(W, H))
+
+    stream = torch.cuda.Stream()
+    dev = api.Device(local_rank, stream=stream.cuda_stream)
+    model = api.Model.new(dev, md)
+    model.set_palette(palette)
+
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world, H, W, 4), dtype=torch.uint8, device="cuda")
+
+    class _Cai:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def one_frame(check=False):
+        fr = api.Frame(dev, W, H)
+        if world > 1:
+            fr.set_shard(rank, world)
+        model.render(fr, M)
+        fr.submit()
+        if check:
+            fr.wait()  # grows the bin queues if needed and validates device flags
+        if world > 1:
+            with torch.cuda.stream(stream):
+                col = torch.as_tensor(_Cai(fr.color_devptr(), W * H * 4), device="cuda").view(H, W, 4)
+                dist.all_gather_into_tensor(gathered, col)
+        fr.close()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    one_frame(check=True)
+    for _ in range(args.warmup):
+        one_frame()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_frame()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt * 1e3 / args.steps
+    mtris = ntris / (ms_per_step * 1e-3) / 1e6
+
+    # ---- roofline: per-stage hipEvent timing on the library's stream, separate from the timed region ----
+    dev.set_profiling(True)
+    stage_ms = {k: 0.0 for k in api.STAGE_NAMES}
+    nprof = max(5, min(50, args.steps))
+    stats = None
+    for _ in range(nprof):
+        fr = api.Frame(dev, W, H)
+        if world > 1:
+            fr.set_shard(rank, world)
+        model.render(fr, M)
+        fr.end()
+        for k, v in fr.timings_ms().items():
+            stage_ms[k] += v / nprof
+        stats = fr.stats()
+        fr.close()
+    dev.set_profiling(False)
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    alg_bytes = algorithmic_bytes(md, W, H, 1)
+    achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 5),
+                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        om = orc.OracleModel(md)
+        threads = os.cpu_count() or 1
+        frames, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds and frames < 64:
+            f = orc.OracleFrame(W, H)
+            t1 = time.perf_counter()
+            f.draw(om, M, palette, nthreads=threads)
+            t_cpu += time.perf_counter() - t1
+            frames += 1
+            f.close()
+        cpu_baseline = {"value": round(ntris * frames / t_cpu / 1e6, 3), "unit": "Mtris/s", "cores": threads, "kind": "port",
+                        "sample": f"{frames} full frames of the same 1M-triangle scene through the CPU oracle "
+                                  f"(oracle/mtr_oracle.c, OpenMP row bands; the reference has no CPU path)"}
+
+    if rank == 0:
+        out = {
+            "metric": "Mtris/sec, 1M-tri 64-bone skinned scene @1920x1080", "value": round(mtris, 2), "unit": "Mtris/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
+                                   "64-bone palette, debug-id shader, %dx%d" % (W, H),
+                       "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if world > 1 else "none"},
+            "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    model.close()
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
