@@ -150,6 +150,9 @@ def main():
         from oracle import oracle as orc
         om = orc.OracleModel(md)
         threads = os.cpu_count() or 1
+        f = orc.OracleFrame(W, H)
+        f.draw(om, M, palette, nthreads=threads)  # untimed: OpenMP pool start-up, page faults
+        f.close()
         frames, t_cpu = 0, 0.0
         while t_cpu < args.cpu_seconds and frames < 64:
             f = orc.OracleFrame(W, H)

@@ -235,19 +235,13 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t rank = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
     uint32_t total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-    uint32_t base = 0;
+    // the run lives at a fixed place (chunk id * MTR_CHUNK_SLOTS): no allocator, no hot counter
+    const uint32_t base = gid * MTR_CHUNK_SLOTS;
     if (lane == 0) {
-        if (total) {
-            base = atomicAdd(&P.fb.counters[CTR_RECORDS], total);
-            if (base + total > P.fb.rec_cap) {  // cannot happen: rec_cap is the hard upper bound
-                atomicOr(&P.fb.counters[CTR_OVERFLOW], 1u);
-                total = 0;
-            }
-        }
         ChunkInfo ci = {base, total};
         P.fb.chunk_info[gid] = ci;
+        if (total) atomicAdd(&P.fb.counters[CTR_REC_SHARDS + (gid & (CTR_NSHARDS - 1))], total);  // statistics only
     }
-    base = __builtin_amdgcn_readfirstlane(base);
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
     if (n_out >= 1) {

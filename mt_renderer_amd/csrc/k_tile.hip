@@ -1,13 +1,16 @@
 // k_tile.hip -- tile raster + depth + fragment shading + blend + write-out (gfx950, wave64).
 //
-// One 256-thread workgroup per 32x32-pixel bin; one wave per row of four 8x8 sub-tiles;
-// lane = pixel, with that pixel's depth and colour held in registers for the whole bin.
-//   1. the bin's segment descriptors are sorted by submission key in LDS (a few dozen items),
-//   2. the concatenated, now fully ordered triangle list is set up 128 triangles at a time into
-//      LDS (integer edge equations relative to the bin origin, top-left bias folded in),
-//   3. each wave walks, per sub-tile and in order, only the triangles whose bbox touches it
-//      (one wave ballot per sub-tile per pass), evaluating the three edge functions per lane,
-//      depth LessEqual (src/model.rs:255-261), the fragment shader (src/shaders/debug_ids.wgsl,
+// One WAVE per 16x16-pixel bin (64-thread workgroups, no workgroup barriers anywhere): bins are
+// the scheduling unit, so the hardware dispatcher balances heavy and light screen regions.
+// lane = pixel of an 8x8 sub-tile; the wave owns the bin's four sub-tiles and keeps every pixel's
+// depth and colour in registers for the whole bin.
+//   1. the bin's segment descriptors (runs of records contributed by one geometry wave, k_bin.hip)
+//      are sorted by submission key with an in-register bitonic network (wave shuffles),
+//   2. the concatenated, now fully ordered triangle list is set up 64 triangles at a time, one per
+//      lane, into LDS (integer edge equations relative to the bin origin, top-left bias folded in),
+//   3. per sub-tile the wave walks, in order, only the triangles whose bbox touches it (one ballot
+//      per sub-tile per pass), evaluating the three edge functions per lane, depth LessEqual
+//      (src/model.rs:255-261), the fragment shader (src/shaders/debug_ids.wgsl,
 //      src/shaders/textured.wgsl + sampler src/texture.rs:33-42) and the blend
 //      (src/model.rs:240-247) in submission order,
 //   4. colour + depth leave the CU once (clear is fused: no separate clear pass).
@@ -15,21 +18,33 @@
 
 namespace mtr {
 
-#define TRI_PASS 128
+#define TRI_PASS 64
 
-struct TriS {
-    // edge i: E_i(lx,ly) = C_i + A_i*lx + B_i*ly   (lx,ly = pixel offset inside the bin)
-    // small class: everything fits i32 and C_i already carries the top-left bias (tl_i - 1);
-    // large class: A/B are unscaled (dy, -dx), C is i64 split in Clo/Chi, bias likewise folded in.
-    int32_t A[3], B[3], Clo[3], Chi[3];
-    int32_t unb[3];  // 1 - tl_i: add back to recover the unbiased edge value
-    uint32_t flags;  // bit0 large
-    float z0, dz1, dz2, rcpA;
-    uint32_t mat, submask;
-    float iw0, diw1, diw2, up0, dup1, dup2, vp0, dvp1, dvp2;
+// per-triangle set-up in LDS.  TriC (64 B) is read by every (triangle, sub-tile) visit as four
+// broadcast ds_read_b128; TriX (64 B) only by textured triangles.
+struct TriC {
+    // edge i: E_i(lx,ly) = C_i + A_i*lx + B_i*ly   (lx,ly = pixel offset inside the bin); C_i already
+    // carries the top-left bias (tl_i - 1).  small class: everything is i32 with A,B pre-scaled by 256;
+    // large class: A/B are the unscaled (dy, -dx), C is i64 with its high word in s_chi.
+    int32_t A0, B0, C0, A1;
+    int32_t B1, C1, A2, B2;
+    int32_t C2;
+    uint32_t flags;  // bit0 large, bit1 textured, bit2 blend, bits 4..6: (1 - tl_i), added back for barycentrics
+    float z0, dz1;
+    float dz2, rcpA;
+    uint32_t rgba8;  // quantised source colour of the debug / constant shaders
     uint32_t pad;
 };
-static_assert(sizeof(TriS) == 32 * 4, "TriS is 32 dwords");
+struct TriX {
+    float iw0, diw1, diw2, up0;
+    float dup1, dup2, vp0, dvp1;
+    float dvp2;
+    uint32_t tw, th, pad;
+    const uint8_t* tex;
+    uint64_t pad2;
+};
+static_assert(sizeof(TriC) == 64 && sizeof(TriX) == 64, "LDS triangle records are 64 B");
+enum { TF_LARGE = 1, TF_TEX = 2, TF_BLEND = 4 };
 
 __device__ __forceinline__ float unorm8f(uint32_t v) { return (float)(v & 0xffu) / 255.0f; }
 __device__ __forceinline__ uint32_t quant8(float x) {
@@ -42,14 +57,18 @@ __device__ __forceinline__ int32_t clamp_texel(float f, uint32_t n) {
     if (f > (float)(n - 1)) f = (float)(n - 1);
     return (int32_t)f;
 }
-__device__ __forceinline__ void texel_f(const DMat& m, int32_t x, int32_t y, float (&o)[4]) {
+struct TexRef {
+    const uint8_t* tex;
+    uint32_t tw, th;
+};
+__device__ __forceinline__ void texel_f(const TexRef& m, int32_t x, int32_t y, float (&o)[4]) {
     uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[(size_t)y * m.tw + (size_t)x];
     o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
 }
 
 // textureSample: clamp-to-edge, mag linear / min nearest, one level (src/texture.rs:21,33-42).
 // du/dx etc. are fine quad differences of the per-lane (u,v): SPEC.md "sampling".
-__device__ __forceinline__ void sample_texture(const DMat& m, float u, float v, bool linear, float (&o)[4]) {
+__device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v, bool linear, float (&o)[4]) {
     const float fw = (float)m.tw, fh = (float)m.th;
     if (!linear) {
         texel_f(m, clamp_texel(floorf(u * fw), m.tw), clamp_texel(floorf(v * fh), m.th), o);
@@ -88,9 +107,20 @@ __device__ __forceinline__ uint32_t blend_store(uint32_t dst, const float (&src)
     return out;
 }
 
-// per-entry set-up by one thread: record -> bin-relative edge equations in LDS
-__device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriS& t) {
+// LDS traffic between lanes of ONE wave: ds operations of a wave complete in order; this only stops
+// the compiler from moving accesses across the hand-off point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// per-entry set-up by one lane: record -> bin-relative edge equations in LDS
+template <bool TEX>
+__device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriC& t, TriX* x,
+                                            int4& chi, uint32_t& submask) {
     const RecA a = P.fb.rec_a[r];
+    const DMat mat = P.mats[a.mat];
     const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
     const long long A2 = (long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]);
     const int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
@@ -98,57 +128,63 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
     const bool large = (xmax - xmin) > 16384 || (ymax - ymin) > 16384;
     const long long Px = (long long)binx0 * 256 + 128, Py = (long long)biny0 * 256 + 128;
     // edge 0: v1->v2, edge 1: v2->v0, edge 2: v0->v1;  E = dy*(Px-Xa) - dx*(Py-Ya)
+    int32_t A[3], B[3], Clo[3], Chi[3];
+    uint32_t flags = large ? TF_LARGE : 0u;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const int ia = (i + 1) % 3, ib = (i + 2) % 3;
         const int32_t dx = X[ib] - X[ia], dy = Y[ib] - Y[ia];
         const int32_t tl = (dy > 0 || (dy == 0 && dx < 0)) ? 1 : 0;
-        long long C = (long long)dy * (Px - X[ia]) - (long long)dx * (Py - Y[ia]) + (tl - 1);
-        t.unb[i] = 1 - tl;
-        if (large) {
-            t.A[i] = dy; t.B[i] = -dx;
-            t.Clo[i] = (int32_t)(uint32_t)(unsigned long long)C;
-            t.Chi[i] = (int32_t)(C >> 32);
-        } else {
-            t.A[i] = dy * 256; t.B[i] = -dx * 256;
-            t.Clo[i] = (int32_t)C; t.Chi[i] = 0;
-        }
+        const long long C = (long long)dy * (Px - X[ia]) - (long long)dx * (Py - Y[ia]) + (tl - 1);
+        flags |= (uint32_t)(1 - tl) << (4 + i);
+        A[i] = large ? dy : dy * 256;
+        B[i] = large ? -dx : -dx * 256;
+        Clo[i] = (int32_t)(uint32_t)(unsigned long long)C;
+        Chi[i] = (int32_t)(C >> 32);
     }
-    t.flags = large ? 1u : 0u;
+    if (TEX && mat.shader == MTR_SH_TEXTURED) flags |= TF_TEX;
+    if (mat.blend) flags |= TF_BLEND;
+    t.A0 = A[0]; t.B0 = B[0]; t.C0 = Clo[0];
+    t.A1 = A[1]; t.B1 = B[1]; t.C1 = Clo[1];
+    t.A2 = A[2]; t.B2 = B[2]; t.C2 = Clo[2];
+    t.flags = flags;
     t.z0 = a.z0; t.dz1 = a.z1 - a.z0; t.dz2 = a.z2 - a.z0;
     t.rcpA = 1.0f / (float)A2;
-    t.mat = a.mat;
-    // sub-tiles (8x8 px) of this bin touched by the pixel-centre bbox
+    t.rgba8 = mat.rgba8;
+    t.pad = 0;
+    chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
+    // sub-tiles (8x8 px) of this bin touched by the pixel-centre bbox: bit = sy*2 + sx
     int32_t px0 = ((xmin + 127) >> 8) - binx0, px1 = ((xmax - 128) >> 8) - binx0;
     int32_t py0 = ((ymin + 127) >> 8) - biny0, py1 = ((ymax - 128) >> 8) - biny0;
-    px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, MTR_BIN - 1); py1 = min(py1, MTR_BIN - 1);
     uint32_t sm = 0;
-    if (px0 <= px1 && py0 <= py1) {
-        const uint32_t rowbits = ((1u << ((px1 >> 3) + 1)) - 1u) & ~((1u << (px0 >> 3)) - 1u);
-        for (int32_t sy = py0 >> 3; sy <= (py1 >> 3); sy++) sm |= rowbits << (4 * sy);
+    if (px0 <= 15 && px1 >= 0 && py0 <= 15 && py1 >= 0) {
+        const uint32_t colbits = (px0 <= 7 ? 1u : 0u) | (px1 >= 8 ? 2u : 0u);
+        if (py0 <= 7) sm |= colbits;
+        if (py1 >= 8) sm |= colbits << 2;
     }
-    t.submask = sm;
-    if (P.mats[a.mat].shader == MTR_SH_TEXTURED) {
+    submask = sm;
+    if (TEX && mat.shader == MTR_SH_TEXTURED) {
         const RecB b = P.fb.rec_b[r];
-        t.iw0 = b.iw0; t.diw1 = b.iw1 - b.iw0; t.diw2 = b.iw2 - b.iw0;
-        t.up0 = b.up0; t.dup1 = b.up1 - b.up0; t.dup2 = b.up2 - b.up0;
-        t.vp0 = b.vp0; t.dvp1 = b.vp1 - b.vp0; t.dvp2 = b.vp2 - b.vp0;
+        x->iw0 = b.iw0; x->diw1 = b.iw1 - b.iw0; x->diw2 = b.iw2 - b.iw0;
+        x->up0 = b.up0; x->dup1 = b.up1 - b.up0; x->dup2 = b.up2 - b.up0;
+        x->vp0 = b.vp0; x->dvp1 = b.vp1 - b.vp0; x->dvp2 = b.vp2 - b.vp0;
+        x->tex = mat.tex; x->tw = mat.tw; x->th = mat.th;
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile(TileParams P) {
-    __shared__ unsigned long long s_sort[MTR_SEG_CAP];
-    __shared__ uint32_t s_off[MTR_SEG_CAP];
-    __shared__ uint32_t s_pre[MTR_SEG_CAP + 1];
-    __shared__ __align__(16) TriS s_tri[TRI_PASS];
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint32_t s_n;
+template <bool TEX>
+__global__ __launch_bounds__(64) void k_tile(TileParams P) {
+    __shared__ __align__(16) TriC s_tc[TRI_PASS];
+    __shared__ __align__(16) TriX s_tx[TEX ? TRI_PASS : 1];
+    __shared__ __align__(16) int4 s_chi[TRI_PASS];
+    __shared__ uint32_t s_mask[TRI_PASS];
+    __shared__ uint32_t s_off[64], s_pre[65];
+    __shared__ Seg s_seg[64];
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lane = threadIdx.x;
     const uint32_t nbx = P.fb.nbx, nbins = nbx * P.fb.nby;
     const uint32_t world = P.fb.shard_world ? P.fb.shard_world : 1u;
-    // XCD-aware bin order: blocks b, b+8, ... share an XCD's L2, give each XCD a contiguous bin range
+    // XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous bin range
     const uint32_t per = (gridDim.x + 7) / 8;
     const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const uint32_t bin = slot * world + P.fb.shard_rank;
@@ -164,189 +200,164 @@ __global__ __launch_bounds__(256) void k_tile(TileParams P) {
     const uint32_t ent_lo = P.fb.bin_start[bin];
     const Seg* segs = P.fb.segs + seg_lo;
 
-    // ---- passes over key ranges [lo, hi): a single pass unless the bin holds > MTR_SEG_CAP segments ----
-    unsigned long long lo = 0, hi = 1ull << 32;
-    if (S > MTR_SEG_CAP) hi = ((1ull << 32) * (MTR_SEG_CAP / 2)) / S + 1;
-    while (S != 0 && lo < (1ull << 32)) {
-        // gather the segments of this key range
-        if (tid == 0) s_n = 0;
-        __syncthreads();
-        if (S <= MTR_SEG_CAP) {
-            for (uint32_t i = tid; i < S; i += 256) {
-                const Seg sg = segs[i];
-                s_sort[i] = ((unsigned long long)sg.key << 32) | i;
-            }
-            if (tid == 0) s_n = S;
+    // ---- key ranges [lo, hi): one pass when the bin holds <= 64 segments ----
+    unsigned long long lo = 0, hi = 1ull << 32, width = 1ull << 32, end = 1ull << 32;
+    if (S > 64) {
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+        for (uint32_t i = lane; i < S; i += 64) { const uint32_t k = segs[i].key; kmin = min(kmin, k); kmax = max(kmax, k); }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d)); }
+        width = ((unsigned long long)(kmax - kmin) + 1) * 40 / S + 1;
+        lo = kmin; hi = lo + width; end = (unsigned long long)kmax + 1;
+    }
+    while (S != 0 && lo < end) {
+        uint32_t n;
+        uint32_t mkey = 0xFFFFFFFFu, moff = 0, mcnt = 0;
+        if (S <= 64) {
+            n = S;
+            if (lane < S) { const Seg sg = segs[lane]; mkey = sg.key; moff = sg.off; mcnt = sg.cnt; }
         } else {
             uint32_t cnt = 0;
-            for (uint32_t i = tid; i < S; i += 256) {
-                const uint32_t k = segs[i].key;
-                if (k >= lo && k < hi) cnt++;
-            }
-            atomicAdd(&s_n, cnt);
-            __syncthreads();
-            if (s_n > MTR_SEG_CAP) {  // too many: halve the range (keys are unique, so this ends)
+            for (uint32_t i = lane; i < S; i += 64) { const uint32_t k = segs[i].key; cnt += (k >= lo && k < hi) ? 1u : 0u; }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, d);
+            if (cnt > 64) {  // keys are unique per bin, so halving always terminates
                 hi = lo + (hi - lo) / 2;
-                __syncthreads();
                 continue;
             }
-            __syncthreads();
-            if (tid == 0) s_n = 0;
-            __syncthreads();
-            for (uint32_t i = tid; i < S; i += 256) {
-                const uint32_t k = segs[i].key;
-                if (k >= lo && k < hi) {
-                    const uint32_t at = atomicAdd(&s_n, 1u);
-                    s_sort[at] = ((unsigned long long)k << 32) | i;
-                }
+            n = cnt;
+            uint32_t filled = 0;
+            for (uint32_t i0 = 0; i0 < S && filled < n; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                Seg sg = {0, 0, 0, 0};
+                bool match = false;
+                if (i < S) { sg = segs[i]; match = sg.key >= lo && sg.key < hi; }
+                const uint64_t m = __ballot(match);
+                if (match) s_seg[filled + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sg;
+                filled += (uint32_t)__popcll(m);
             }
+            wave_lds_sync();
+            if (lane < n) { const Seg sg = s_seg[lane]; mkey = sg.key; moff = sg.off; mcnt = sg.cnt; }
+            wave_lds_sync();
         }
-        __syncthreads();
-        const uint32_t n = s_n;
         if (n) {
-            // bitonic sort of n (padded to a power of two) keys
-            uint32_t np2 = 1;
-            while (np2 < n) np2 <<= 1;
-            for (uint32_t i = n + tid; i < np2; i += 256) s_sort[i] = ~0ull;
-            __syncthreads();
-            for (uint32_t k = 2; k <= np2; k <<= 1)
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = tid; i < np2; i += 256) {
-                        const uint32_t ixj = i ^ j;
-                        if (ixj > i) {
-                            const unsigned long long a = s_sort[i], b = s_sort[ixj];
-                            const bool up = (i & k) == 0;
-                            if ((a > b) == up) { s_sort[i] = b; s_sort[ixj] = a; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            // sorted (offset, count) + exclusive prefix of counts
-            uint32_t offs[MTR_SEG_CAP / 256], cnts[MTR_SEG_CAP / 256], tsum = 0;
+            // in-register bitonic sort by key (unused lanes hold key 0xFFFFFFFF and sink to the end)
 #pragma unroll
-            for (int e = 0; e < MTR_SEG_CAP / 256; e++) {
-                const uint32_t k = tid * (MTR_SEG_CAP / 256) + e;
-                offs[e] = 0; cnts[e] = 0;
-                if (k < n) {
-                    const Seg sg = segs[(uint32_t)s_sort[k]];
-                    offs[e] = sg.off; cnts[e] = sg.cnt;
+            for (uint32_t k = 2; k <= 64; k <<= 1)
+#pragma unroll
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    const uint32_t okey = (uint32_t)__shfl_xor((int)mkey, (int)j);
+                    const uint32_t ooff = (uint32_t)__shfl_xor((int)moff, (int)j);
+                    const uint32_t ocnt = (uint32_t)__shfl_xor((int)mcnt, (int)j);
+                    const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+                    const bool take = (lower == up) ? (okey < mkey) : (okey > mkey);
+                    if (take) { mkey = okey; moff = ooff; mcnt = ocnt; }
                 }
-                tsum += cnts[e];
-            }
-            uint32_t inc = tsum;
+            // exclusive prefix of the counts over the sorted segments
+            uint32_t inc = mcnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(inc, d);
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
                 if ((int)lane >= d) inc += t;
             }
-            if (lane == 63) s_wsum[wave] = inc;
-            __syncthreads();
-            uint32_t run = inc - tsum;
-            for (uint32_t w = 0; w < wave; w++) run += s_wsum[w];
-#pragma unroll
-            for (int e = 0; e < MTR_SEG_CAP / 256; e++) {
-                const uint32_t k = tid * (MTR_SEG_CAP / 256) + e;
-                if (k < n) { s_off[k] = offs[e]; s_pre[k] = run; }
-                run += cnts[e];
-            }
-            if (tid == 255) s_pre[n] = run;  // thread 255 holds the grand total (k >= n adds 0)
-            __syncthreads();
-            const uint32_t N = s_pre[n];
+            s_off[lane] = moff;
+            s_pre[lane] = inc - mcnt;
+            if (lane == 63) s_pre[64] = inc;
+            wave_lds_sync();
+            const uint32_t N = s_pre[64];
 
-            // ---- ordered triangle list of this pass, TRI_PASS at a time ----
+            // ---- ordered triangle list of this range, 64 at a time ----
             for (uint32_t e0 = 0; e0 < N; e0 += TRI_PASS) {
                 const uint32_t cntp = min((uint32_t)TRI_PASS, N - e0);
-                if (tid < cntp) {
-                    const uint32_t e = e0 + tid;
-                    uint32_t a = 0, b = n;  // largest k with s_pre[k] <= e
-                    while (b - a > 1) {
+                if (lane < cntp) {
+                    const uint32_t e = e0 + lane;
+                    uint32_t a = 0, b = 64;  // largest k with s_pre[k] <= e (zero-count tails never win)
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
                         const uint32_t mid = (a + b) >> 1;
                         if (s_pre[mid] <= e) a = mid; else b = mid;
                     }
                     const uint32_t r = P.fb.entries[ent_lo + s_off[a] + (e - s_pre[a])];
-                    setup_entry(P, r, binx0, biny0, s_tri[tid]);
+                    setup_entry<TEX>(P, r, binx0, biny0, s_tc[lane], TEX ? &s_tx[lane] : nullptr, s_chi[lane], s_mask[lane]);
                 }
-                __syncthreads();
+                wave_lds_sync();
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const uint32_t s = wave * 4 + i;
-                    const int32_t lx = (int32_t)((s & 3) * 8 + (lane & 7)), ly = (int32_t)((s >> 2) * 8 + (lane >> 3));
+                    const int32_t lx = (int32_t)((i & 1) * 8 + (lane & 7)), ly = (int32_t)((i >> 1) * 8 + (lane >> 3));
                     const bool in_vp = (uint32_t)(binx0 + lx) < P.fb.W && (uint32_t)(biny0 + ly) < P.fb.H;
-                    for (uint32_t half = 0; half * 64 < cntp; half++) {
-                        const uint32_t ti = half * 64 + lane;
-                        uint64_t m = __ballot(ti < cntp && ((s_tri[ti].submask >> s) & 1u));
-                        while (m) {
-                            const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)m) - 1 + half * 64);
-                            m &= m - 1;
-                            const TriS& T = s_tri[t];
-                            bool inside;
-                            float e1f, e2f;
-                            if (!(T.flags & 1u)) {
-                                const int32_t eb0 = T.Clo[0] + __mul24(T.A[0], lx) + __mul24(T.B[0], ly);
-                                const int32_t eb1 = T.Clo[1] + __mul24(T.A[1], lx) + __mul24(T.B[1], ly);
-                                const int32_t eb2 = T.Clo[2] + __mul24(T.A[2], lx) + __mul24(T.B[2], ly);
-                                inside = (eb0 | eb1 | eb2) >= 0;
-                                e1f = (float)(eb1 + T.unb[1]);
-                                e2f = (float)(eb2 + T.unb[2]);
-                            } else {
-                                const long long X = (long long)lx * 256, Y = (long long)ly * 256;
-                                long long eb[3];
-#pragma unroll
-                                for (int k = 0; k < 3; k++) {
-                                    const long long C = ((long long)T.Chi[k] << 32) | (unsigned long long)(uint32_t)T.Clo[k];
-                                    eb[k] = C + (long long)T.A[k] * X + (long long)T.B[k] * Y;
-                                }
-                                inside = (eb[0] | eb[1] | eb[2]) >= 0;
-                                e1f = (float)(eb[1] + T.unb[1]);
-                                e2f = (float)(eb[2] + T.unb[2]);
-                            }
-                            const float b1 = e1f * T.rcpA, b2 = e2f * T.rcpA;
-                            const float z = fmaf(b2, T.dz2, fmaf(b1, T.dz1, T.z0));
-                            const DMat& M = P.mats[T.mat];
-                            if (M.shader != MTR_SH_TEXTURED) {
-                                const bool pass = inside && in_vp && z >= 0.0f && z <= 1.0f && z <= dep[i];
-                                if (pass) { dep[i] = z; col[i] = M.rgba8; }
-                            } else {
-                                // every lane evaluates (u,v) so quad differences exist for helper pixels too
-                                const float iw = fmaf(b2, T.diw2, fmaf(b1, T.diw1, T.iw0));
-                                const float up = fmaf(b2, T.dup2, fmaf(b1, T.dup1, T.up0));
-                                const float vp = fmaf(b2, T.dvp2, fmaf(b1, T.dvp1, T.vp0));
-                                const float u = up / iw, v = vp / iw;
-                                const float dudx = __shfl(u, (int)(lane | 1)) - __shfl(u, (int)(lane & ~1u));
-                                const float dvdx = __shfl(v, (int)(lane | 1)) - __shfl(v, (int)(lane & ~1u));
-                                const float dudy = __shfl(u, (int)(lane | 8)) - __shfl(u, (int)(lane & ~8u));
-                                const float dvdy = __shfl(v, (int)(lane | 8)) - __shfl(v, (int)(lane & ~8u));
-                                const float fw = (float)M.tw, fh = (float)M.th;
-                                const bool linear = (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) &&
-                                                    (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
-                                const bool pass = inside && in_vp && z >= 0.0f && z <= 1.0f && z <= dep[i];
-                                if (pass) {
-                                    dep[i] = z;
-                                    float src[4];
-                                    sample_texture(M, u, v, linear, src);
-                                    col[i] = blend_store(col[i], src, M.blend != 0);
-                                }
+                    uint64_t m = __ballot(lane < cntp && ((s_mask[lane] >> i) & 1u));
+                    while (m) {
+                        const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)m) - 1);
+                        m &= m - 1;
+                        const int4* tc = reinterpret_cast<const int4*>(&s_tc[t]);
+                        const int4 q0 = tc[0], q1 = tc[1], q2 = tc[2], q3 = tc[3];
+                        const int32_t A0 = q0.x, B0 = q0.y, C0 = q0.z, A1 = q0.w, B1 = q1.x, C1 = q1.y, A2 = q1.z, B2 = q1.w, C2 = q2.x;
+                        const uint32_t flags = (uint32_t)q2.y;
+                        const float z0 = __int_as_float(q2.z), dz1 = __int_as_float(q2.w), dz2 = __int_as_float(q3.x),
+                                    rcpA = __int_as_float(q3.y);
+                        bool inside;
+                        float e1f, e2f;
+                        if (!(flags & TF_LARGE)) {
+                            const int32_t eb0 = C0 + __mul24(A0, lx) + __mul24(B0, ly);
+                            const int32_t eb1 = C1 + __mul24(A1, lx) + __mul24(B1, ly);
+                            const int32_t eb2 = C2 + __mul24(A2, lx) + __mul24(B2, ly);
+                            inside = (eb0 | eb1 | eb2) >= 0;
+                            e1f = (float)(eb1 + (int32_t)((flags >> 5) & 1u));
+                            e2f = (float)(eb2 + (int32_t)((flags >> 6) & 1u));
+                        } else {
+                            const int4 ch = s_chi[t];
+                            const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
+                            const long long c0 = ((long long)ch.x << 32) | (unsigned long long)(uint32_t)C0;
+                            const long long c1 = ((long long)ch.y << 32) | (unsigned long long)(uint32_t)C1;
+                            const long long c2 = ((long long)ch.z << 32) | (unsigned long long)(uint32_t)C2;
+                            const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
+                            const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
+                            const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
+                            inside = (eb0 | eb1 | eb2) >= 0;
+                            e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
+                            e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
+                        }
+                        const float b1 = e1f * rcpA, b2 = e2f * rcpA;
+                        const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
+                        const bool pass = inside && in_vp && z >= 0.0f && z <= 1.0f && z <= dep[i];
+                        if (!TEX || !(flags & TF_TEX)) {
+                            if (pass) { dep[i] = z; col[i] = (uint32_t)q3.z; }
+                        } else {
+                            // every lane evaluates (u,v) so quad differences exist for helper pixels too
+                            const TriX& Xt = s_tx[TEX ? t : 0];
+                            const float iw = fmaf(b2, Xt.diw2, fmaf(b1, Xt.diw1, Xt.iw0));
+                            const float up = fmaf(b2, Xt.dup2, fmaf(b1, Xt.dup1, Xt.up0));
+                            const float vp = fmaf(b2, Xt.dvp2, fmaf(b1, Xt.dvp1, Xt.vp0));
+                            const float u = up / iw, v = vp / iw;
+                            const float dudx = __shfl(u, (int)(lane | 1)) - __shfl(u, (int)(lane & ~1u));
+                            const float dvdx = __shfl(v, (int)(lane | 1)) - __shfl(v, (int)(lane & ~1u));
+                            const float dudy = __shfl(u, (int)(lane | 8)) - __shfl(u, (int)(lane & ~8u));
+                            const float dvdy = __shfl(v, (int)(lane | 8)) - __shfl(v, (int)(lane & ~8u));
+                            const TexRef tr = {Xt.tex, Xt.tw, Xt.th};
+                            const float fw = (float)tr.tw, fh = (float)tr.th;
+                            const bool linear = (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) &&
+                                                (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
+                            if (pass) {
+                                dep[i] = z;
+                                float src[4];
+                                sample_texture(tr, u, v, linear, src);
+                                col[i] = blend_store(col[i], src, (flags & TF_BLEND) != 0);
                             }
                         }
                     }
                 }
-                __syncthreads();
+                wave_lds_sync();
             }
         }
         lo = hi;
-        if (S > MTR_SEG_CAP) {
-            unsigned long long width = ((1ull << 32) * (MTR_SEG_CAP / 2)) / S + 1;
-            hi = lo + width;
-            if (hi > (1ull << 32)) hi = 1ull << 32;
-        }
-        __syncthreads();
+        hi = lo + width;
+        if (hi > (1ull << 32)) hi = 1ull << 32;
     }
 
     // ---- write-out: the only framebuffer traffic of the frame ----
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t s = wave * 4 + i;
-        const uint32_t x = (uint32_t)binx0 + (s & 3) * 8 + (lane & 7), y = (uint32_t)biny0 + (s >> 2) * 8 + (lane >> 3);
+        const uint32_t x = (uint32_t)binx0 + (i & 1) * 8 + (lane & 7), y = (uint32_t)biny0 + (i >> 1) * 8 + (lane >> 3);
         if (x < P.fb.W && y < P.fb.H) {
             const size_t pi = (size_t)y * P.fb.W + x;
             reinterpret_cast<uint32_t*>(P.color)[pi] = col[i];
@@ -357,11 +368,12 @@ __global__ __launch_bounds__(256) void k_tile(TileParams P) {
 
 }  // namespace mtr
 
-void mtr_launch_tile(const TileParams& p, hipStream_t s) {
+void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s) {
     const uint32_t nbins = p.fb.nbx * p.fb.nby;
     const uint32_t world = p.fb.shard_world ? p.fb.shard_world : 1u;
     uint32_t mine = (nbins + world - 1 - p.fb.shard_rank) / world;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
-    hipLaunchKernelGGL(mtr::k_tile, dim3(grid), dim3(256), 0, s, p);
+    if (textured) hipLaunchKernelGGL(mtr::k_tile<true>, dim3(grid), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(mtr::k_tile<false>, dim3(grid), dim3(64), 0, s, p);
 }

@@ -780,7 +780,9 @@ static int32_t run_frame(mtr_frame* f) {
     TileParams tp{};
     tp.fb = fb; tp.mats = d->mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
-    mtr_launch_tile(tp, d->stream);
+    bool any_textured = false;
+    for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
+    mtr_launch_tile(tp, any_textured, d->stream);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], d->stream));
     HIPCHK(d, hipGetLastError());
     f->stats = mtr_frame_stats{};
@@ -809,7 +811,8 @@ int32_t mtr_frame_wait(mtr_frame* f) {
         uint32_t ctr[CTR_NUM];
         HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        f->stats.tris_setup = ctr[CTR_RECORDS];
+        f->stats.tris_setup = 0;
+        for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[CTR_REC_SHARDS + k];
         f->stats.bin_entries = ctr[CTR_ENTRIES];
         f->stats.segments = ctr[CTR_SEGS];
         if (!ctr[CTR_OVERFLOW]) {

@@ -13,14 +13,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define MTR_BIN 32             // screen bin edge in pixels (one workgroup of the tile kernel)
-#define MTR_BIN_SHIFT 5
+#define MTR_BIN 16             // screen bin edge in pixels (one wave of the tile kernel)
+#define MTR_BIN_SHIFT 4
 #define MTR_SUB 8              // sub-tile edge: one wave64 = one 8x8 pixel block
 #define MTR_CHUNK_NEW 62       // strip positions that complete a triangle per geometry wave
 #define MTR_CHUNK_SLOTS 124    // worst case records per chunk (near clip: 2 per position)
 #define MTR_GUARD_BAND 1048576.0f
-#define MTR_SEG_CAP 2048       // segments sorted in LDS per pass by the tile kernel
-#define MTR_TILE_CHUNK 256     // triangles set up per tile-kernel pass
 
 enum { MTR_SH_DEBUG = 0, MTR_SH_TEXTURED = 1, MTR_SH_CONST = 2 };
 
@@ -78,7 +76,8 @@ struct Seg {             // 16 B
     uint32_t pad;
 };
 
-enum { CTR_RECORDS = 0, CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_NUM = 8 };
+// counters[]: [1] entries, [2] segments, [3] overflow flags, [16..79] surviving-triangle count shards
+enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_REC_SHARDS = 16, CTR_NSHARDS = 64, CTR_NUM = 80 };
 
 struct FrameBuffers {
     RecHdr* rec_hdr;
@@ -126,7 +125,7 @@ struct TileParams {
 void mtr_launch_geom(const GeomParams& p, hipStream_t s);
 void mtr_launch_scan(const FrameBuffers& fb, hipStream_t s);
 void mtr_launch_fill(const FrameBuffers& fb, uint32_t total_chunks, hipStream_t s);
-void mtr_launch_tile(const TileParams& p, hipStream_t s);
+void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s);
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s);
 void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
 void mtr_launch_bc7_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);

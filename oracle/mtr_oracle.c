@@ -850,25 +850,46 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
             if (su[i].valid) frags += raster_tri(f, &su[i], fs, 0, (int32_t)f->h);
     } else {
 #ifdef _OPENMP
-#pragma omp parallel num_threads(nthreads) reduction(+ : frags)
-        {
-            int nt = omp_get_num_threads(), id = omp_get_thread_num();
-            /* interleaved 8-row bands: every pixel row is owned by exactly one thread, and each
-             * thread walks the set-ups in submission order, so results equal the scalar path */
-            for (int32_t band = id * 8; band < (int32_t)f->h; band += nt * 8) {
-                int32_t hi = band + 8 > (int32_t)f->h ? (int32_t)f->h : band + 8;
-                for (size_t i = 0; i < 2 * (size_t)index_num; i++) {
-                    if (!su[i].valid) continue;
-                    int32_t ymin = su[i].Y[0], ymax = su[i].Y[0];
-                    for (int k = 1; k < 3; k++) {
-                        if (su[i].Y[k] < ymin) ymin = su[i].Y[k];
-                        if (su[i].Y[k] > ymax) ymax = su[i].Y[k];
-                    }
-                    if (((ymax - 128) >> 8) < band || ((ymin + 127) >> 8) >= hi) continue;
-                    frags += raster_tri(f, &su[i], fs, band, hi);
-                }
+        /* 8-row bands: every pixel row is owned by exactly one band, each band walks its own list of
+         * set-ups in submission order (lists built serially by a counting sort), so results equal
+         * the scalar path whatever the thread count */
+        const int32_t BH = 8, nband = ((int32_t)f->h + BH - 1) / BH;
+        uint32_t *bstart = (uint32_t *)calloc((size_t)nband + 1, sizeof(uint32_t));
+        for (size_t i = 0; i < 2 * (size_t)index_num; i++) {
+            if (!su[i].valid) continue;
+            int32_t ymin = su[i].Y[0], ymax = su[i].Y[0];
+            for (int k = 1; k < 3; k++) {
+                if (su[i].Y[k] < ymin) ymin = su[i].Y[k];
+                if (su[i].Y[k] > ymax) ymax = su[i].Y[k];
             }
+            int32_t b0 = ((ymin + 127) >> 8), b1 = ((ymax - 128) >> 8);
+            if (b0 < 0) b0 = 0;
+            if (b1 > (int32_t)f->h - 1) b1 = (int32_t)f->h - 1;
+            for (int32_t b = b0 / BH; b <= b1 / BH; b++) bstart[b + 1]++;
         }
+        for (int32_t b = 0; b < nband; b++) bstart[b + 1] += bstart[b];
+        uint32_t *blist = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)bstart[nband] + 1));
+        uint32_t *bfill = (uint32_t *)calloc((size_t)nband, sizeof(uint32_t));
+        for (size_t i = 0; i < 2 * (size_t)index_num; i++) {
+            if (!su[i].valid) continue;
+            int32_t ymin = su[i].Y[0], ymax = su[i].Y[0];
+            for (int k = 1; k < 3; k++) {
+                if (su[i].Y[k] < ymin) ymin = su[i].Y[k];
+                if (su[i].Y[k] > ymax) ymax = su[i].Y[k];
+            }
+            int32_t b0 = ((ymin + 127) >> 8), b1 = ((ymax - 128) >> 8);
+            if (b0 < 0) b0 = 0;
+            if (b1 > (int32_t)f->h - 1) b1 = (int32_t)f->h - 1;
+            for (int32_t b = b0 / BH; b <= b1 / BH; b++) blist[bstart[b] + bfill[b]++] = (uint32_t)i;
+        }
+#pragma omp parallel for num_threads(nthreads) reduction(+ : frags) schedule(dynamic, 1)
+        for (int32_t b = 0; b < nband; b++) {
+            int32_t lo = b * BH, hi = lo + BH > (int32_t)f->h ? (int32_t)f->h : lo + BH;
+            for (uint32_t k = bstart[b]; k < bstart[b + 1]; k++) frags += raster_tri(f, &su[blist[k]], fs, lo, hi);
+        }
+        free(bfill);
+        free(blist);
+        free(bstart);
 #else
         for (size_t i = 0; i < 2 * (size_t)index_num; i++)
             if (su[i].valid) frags += raster_tri(f, &su[i], fs, 0, (int32_t)f->h);
