@@ -77,13 +77,14 @@ def main():
     model = api.Model.new(dev, md)
     model.set_palette(palette)
 
-    gathered = None
+    # N > 1: each rank renders bins (bin % N == rank), packs them bin-major (csrc/k_shard.hip), one RCCL
+    # all-gather over xGMI exchanges W*H*4/N bytes per rank, one unpack kernel rebuilds the linear frame
+    shard = gathered = final = None
     if world > 1:
-        gathered = torch.empty((world, H, W, 4), dtype=torch.uint8, device="cuda")
-
-    class _Cai:
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        nbytes = int(api.lib.mtr_shard_bytes(W, H, world))
+        shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+        final = torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")
 
     def one_frame(check=False):
         fr = api.Frame(dev, W, H)
@@ -94,9 +95,10 @@ def main():
         if check:
             fr.wait()  # grows the bin queues if needed and validates device flags
         if world > 1:
+            fr.pack_color_shard(shard.data_ptr(), shard.numel())
             with torch.cuda.stream(stream):
-                col = torch.as_tensor(_Cai(fr.color_devptr(), W * H * 4), device="cuda").view(H, W, 4)
-                dist.all_gather_into_tensor(gathered, col)
+                dist.all_gather_into_tensor(gathered, shard)
+            dev.unpack_color_shards(gathered.data_ptr(), world, W, H, final.data_ptr())
         fr.close()
 
     def sync():
@@ -149,7 +151,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         om = orc.OracleModel(md)
-        threads = os.cpu_count() or 1
+        # the GPU box gives one-GPU jobs a 16-CPU share; more OpenMP threads than that only spin
+        threads = max(1, min(len(os.sched_getaffinity(0)), 16))
         f = orc.OracleFrame(W, H)
         f.draw(om, M, palette, nthreads=threads)  # untimed: OpenMP pool start-up, page faults
         f.close()

@@ -150,6 +150,14 @@ int32_t mtr_frame_read_color(mtr_frame *frame, void *rgba8, size_t len);  /* wid
 int32_t mtr_frame_read_depth(mtr_frame *frame, float *depth, size_t count); /* width*height */
 void *mtr_frame_color_devptr(mtr_frame *frame); /* RGBA8 in HBM, row-major */
 void *mtr_frame_depth_devptr(mtr_frame *frame); /* f32 in HBM, row-major */
+/* multi-GPU exchange helpers (device pointers, enqueued on the device's stream):
+ * pack: this frame's own bins (bin % world == rank), bin-major, 16x16 RGBA8 each, into dst
+ *       (mtr_shard_bytes(width,height,world) bytes) = the all-gather send buffer;
+ * unpack: gathered = world such blocks in rank order -> linear RGBA8 width*height at dst. */
+size_t mtr_shard_bytes(uint32_t width, uint32_t height, uint32_t world);
+int32_t mtr_frame_pack_color_shard(mtr_frame *frame, void *dst_dev, size_t dst_bytes);
+int32_t mtr_device_unpack_color_shards(mtr_device *dev, const void *gathered_dev, uint32_t world,
+                                       uint32_t width, uint32_t height, void *dst_dev);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
 void mtr_frame_destroy(mtr_frame *frame);

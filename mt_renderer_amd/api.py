@@ -31,7 +31,8 @@ EXPORTED_SYMBOLS = [
     "mtr_frame_draw_batch", "mtr_frame_draw_instances", "mtr_frame_draw_overlay_cubes", "mtr_frame_submit",
     "mtr_frame_wait", "mtr_frame_end", "mtr_frame_read_color", "mtr_frame_read_depth", "mtr_frame_color_devptr",
     "mtr_frame_depth_devptr", "mtr_frame_get_stats", "mtr_frame_get_timings", "mtr_frame_destroy",
-    "mtr_model_vertex_stage", "mtr_crc32",
+    "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
+    "mtr_device_unpack_color_shards",
 ]
 
 
@@ -103,6 +104,9 @@ def _load() -> C.CDLL:
         "mtr_frame_destroy": (None, [vp]),
         "mtr_model_vertex_stage": (i32, [vp, sz, vp, vp, vp]),
         "mtr_crc32": (u32, [vp, sz, u32]),
+        "mtr_shard_bytes": (sz, [u32, u32, u32]),
+        "mtr_frame_pack_color_shard": (i32, [vp, vp, sz]),
+        "mtr_device_unpack_color_shards": (i32, [vp, vp, u32, u32, u32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -141,6 +145,11 @@ class Device:
     def check(self, rc: int):
         if rc:
             raise MtrError(rc, (lib.mtr_last_error(self._h) or b"").decode())
+
+    def unpack_color_shards(self, gathered_devptr: int, world: int, width: int, height: int, dst_devptr: int):
+        """gathered [rank][k][16][16] RGBA8 blocks (device) -> linear RGBA8 framebuffer (device)."""
+        self.check(lib.mtr_device_unpack_color_shards(self._h, C.c_void_p(gathered_devptr), world, width, height,
+                                                      C.c_void_p(dst_devptr)))
 
     def set_profiling(self, on: bool):
         self.check(lib.mtr_device_set_profiling(self._h, 1 if on else 0))
@@ -325,6 +334,10 @@ class Frame:
         out = np.zeros((self.h, self.w), dtype=np.float32)
         self.dev.check(lib.mtr_frame_read_depth(self._h, _p(out), out.size))
         return out
+
+    def pack_color_shard(self, dst_devptr: int, dst_bytes: int):
+        """this rank's bins, bin-major, into the all-gather send buffer (device pointer)."""
+        self.dev.check(lib.mtr_frame_pack_color_shard(self._h, C.c_void_p(dst_devptr), dst_bytes))
 
     def color_devptr(self) -> int:
         return int(lib.mtr_frame_color_devptr(self._h) or 0)

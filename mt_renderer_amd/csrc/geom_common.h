@@ -111,8 +111,8 @@ __device__ __forceinline__ VOut shade_vertex(const uint8_t* vbuf, const DPrim& p
 
 // ---------------------------------------------------------------------------------------------
 // bin iteration shared by k_geom (count) and k_fill (fill): one round = up to 64 records, one per
-// lane, in record order.  Lanes whose current bin equals the first active lane's bin form a group;
-// f(bin, group_mask, is_member) runs once per group, groups in a deterministic order, so both
+// lane, in record order.  Lanes whose current bin equals the wave-minimum current bin form a group;
+// f(bin, group_mask, is_member) runs once per group, groups in increasing bin order, so both
 // kernels see identical (bin, count) sequences.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool bin_owned(uint32_t bin, uint32_t rank, uint32_t world) {
@@ -129,9 +129,14 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
     for (;;) {
         uint64_t m_act = __ballot(act);
         if (!m_act) break;
+        // every lane walks its bins in increasing order and the wave always serves the SMALLEST current
+        // bin, so each bin is served exactly once per round, by all of its lanes together, in lane
+        // (= submission) order: one ordered segment per (chunk, round, bin)
         uint32_t mybin = by * nbx + bx;
-        uint32_t first = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)m_act) - 1);
-        uint32_t b = __builtin_amdgcn_readlane(mybin, first);
+        uint32_t b = act ? mybin : 0xFFFFFFFFu;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, d));
+        b = __builtin_amdgcn_readfirstlane(b);
         bool hit = act && mybin == b;
         uint64_t m = __ballot(hit);
         f(b, m, hit);

@@ -250,7 +250,11 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                     const uint32_t ooff = (uint32_t)__shfl_xor((int)moff, (int)j);
                     const uint32_t ocnt = (uint32_t)__shfl_xor((int)mcnt, (int)j);
                     const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-                    const bool take = (lower == up) ? (okey < mkey) : (okey > mkey);
+                    // one (chunk, round) can contribute several runs to a bin (k_bin.hip groups lanes by
+                    // their CURRENT bin); their offsets were handed out in program order by one wave,
+                    // so (key, offset) is a total submission order
+                    const unsigned long long mk = ((unsigned long long)mkey << 32) | moff, ok = ((unsigned long long)okey << 32) | ooff;
+                    const bool take = (lower == up) ? (ok < mk) : (ok > mk);
                     if (take) { mkey = okey; moff = ooff; mcnt = ocnt; }
                 }
             // exclusive prefix of the counts over the sorted segments

@@ -864,6 +864,35 @@ int32_t mtr_frame_read_depth(mtr_frame* f, float* depth, size_t count) {
 void* mtr_frame_color_devptr(mtr_frame* f) { return f ? f->fb.color : nullptr; }
 void* mtr_frame_depth_devptr(mtr_frame* f) { return f ? f->fb.depth : nullptr; }
 
+size_t mtr_shard_bytes(uint32_t w, uint32_t h, uint32_t world) {
+    if (world == 0) return 0;
+    const size_t nbins = (size_t)((w + MTR_BIN - 1) / MTR_BIN) * ((h + MTR_BIN - 1) / MTR_BIN);
+    return (nbins + world - 1) / world * (MTR_BIN * MTR_BIN * 4);
+}
+
+int32_t mtr_frame_pack_color_shard(mtr_frame* f, void* dst_dev, size_t dst_bytes) {
+    if (!f || !dst_dev) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (!f->submitted) return fail(d, MTR_E_INVALID, "frame not submitted");
+    if (dst_bytes < mtr_shard_bytes(f->w, f->h, f->shard_world)) return fail(d, MTR_E_INVALID, "shard buffer too small");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    mtr_launch_pack_shard(f->fb.color, static_cast<uint8_t*>(dst_dev), f->w, f->h, f->shard_rank, f->shard_world, d->stream);
+    HIPCHK(d, hipGetLastError());
+    return MTR_OK;
+}
+
+int32_t mtr_device_unpack_color_shards(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h,
+                                       void* dst_dev) {
+    if (!d || !gathered_dev || !dst_dev) return MTR_E_INVALID;
+    if (world == 0 || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad unpack arguments");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    mtr_launch_unpack_shards(static_cast<const uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev), w, h, world, d->stream);
+    HIPCHK(d, hipGetLastError());
+    return MTR_OK;
+}
+
 int32_t mtr_frame_get_stats(mtr_frame* f, mtr_frame_stats* out) {
     if (!f || !out) return MTR_E_INVALID;
     int32_t rc = mtr_frame_wait(f);

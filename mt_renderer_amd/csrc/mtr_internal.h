@@ -129,3 +129,5 @@ void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s);
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s);
 void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
 void mtr_launch_bc7_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
+void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, hipStream_t s);
+void mtr_launch_unpack_shards(const uint8_t* gathered, uint8_t* color, uint32_t W, uint32_t H, uint32_t world, hipStream_t s);

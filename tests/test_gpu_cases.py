@@ -1,0 +1,342 @@
+"""-m gpu: edge cases of the draw path, HIP (through the C ABI) vs the CPU oracle, bit for bit:
+fill rule, strips / restart, depth ties, clipping, big triangles (64-bit edge path), every vertex
+format of the reference's table, textures (RGBA8 / BC1 / BC7, linear + nearest, blending), instancing,
+the debug overlay, many-segment bins, sharded bins and error behaviour."""
+import numpy as np
+import pytest
+
+from mt_renderer_amd import scene, sharding
+from oracle import oracle as orc
+from tests.helpers import assert_same, render_gpu, render_oracle
+from tests.pixel_scenes import pixel_model, pixel_to_ndc_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(dev, w, h, draws, **kw):
+    g = render_gpu(dev, w, h, draws, **kw)
+    assert_same(g, render_oracle(w, h, draws, **kw), "case")
+    return g
+
+
+def _px(dev, prims, w=64, h=64, textures=None, parts_disp=None, **kw):
+    md = pixel_model(prims, textures, parts_disp)
+    return _both(dev, w, h, [dict(md=md, M=pixel_to_ndc_matrix(w, h))], **kw)
+
+
+def _quad(x0, y0, x1, y1, z, u0=0.0, v0=0.0, u1=1.0, v1=1.0, tex=0, did=0):
+    v = [(x0, y0, z, u0, v0), (x0, y1, z, u0, v1), (x1, y1, z, u1, v1), (x1, y0, z, u1, v0)]
+    return dict(verts=v, indices=[0, 1, 2, 0, 2, 3], texture=tex, debug_id=did)
+
+
+def test_empty_frame_is_clear(gpu_device):
+    from mt_renderer_amd import api
+    fr = api.Frame(gpu_device, 70, 33, (0.25, 0.5, 0.75, 1.0), 0.5)
+    fr.end()
+    c, d = fr.color(), fr.depth()
+    fr.close()
+    assert (c == np.array([64, 128, 191, 255], dtype=np.uint8)).all() and (d == np.float32(0.5)).all()
+
+
+def test_fill_rule_cases(gpu_device):
+    _px(gpu_device, [dict(verts=[(0, 0, .5), (0, 8, .5), (8, 0, .5)], indices=[0, 1, 2])])
+    v = [(2.5, 2.5, .5), (2.5, 10.5, .5), (10.5, 10.5, .5), (10.5, 2.5, .5)]
+    g = _px(gpu_device, [dict(verts=v, indices=[0, 1, 2, 0, 2, 3])])
+    assert (g[1] < 1).sum() == 64
+    # a fan around an off-grid centre with vertices on pixel centres and pixel corners
+    c = (17.3, 19.8, .4)
+    ring = [(30.5, 20.5, .4), (25, 31, .4), (12.5, 30.5, .4), (5, 17, .4), (11.5, 6.5, .4), (24, 5, .4)]
+    idx = []
+    for k in range(6):
+        idx += [0, 1 + (k + 1) % 6, 1 + k]
+    _px(gpu_device, [dict(verts=[c] + ring, indices=idx)])
+
+
+def test_strips_restart_parity_and_index_base(gpu_device):
+    v = [(0, 0, .5), (0, 8, .5), (8, 0, .5), (8, 8, .5), (16, 0, .5), (16, 8, .5), (24, 0, .3), (24, 8, .3)]
+    S = scene.TOPO_STRIP
+    _px(gpu_device, [dict(verts=v, indices=[0, 1, 2, 3, 4, 5, 6, 7], topology=S)])
+    _px(gpu_device, [dict(verts=v, indices=[0, 1, 2, 0xFFFF, 2, 3, 4, 5, 0xFFFF, 0xFFFF, 4, 5, 6, 7, 0xFFFF], topology=S)])
+    _px(gpu_device, [dict(verts=v, indices=[0, 1, 0xFFFF, 2, 3, 0xFFFF, 4], topology=S)])
+    _px(gpu_device, [dict(verts=v, indices=[0, 1, 2, 3, 4, 5], topology=S, index_base=2)])
+    # out-of-range vertices drop their triangles only
+    _px(gpu_device, [dict(verts=v[:4], indices=[0, 1, 2, 0, 1, 9, 1, 3, 2])])
+    # a long strip with restarts at awkward places relative to the 62-position geometry chunks
+    rng = np.random.default_rng(5)
+    n = 400
+    vv = [(float(4 + (k // 2) * 0.3), float(8 + 20 * (k & 1)), 0.5) for k in range(n)]
+    idx = list(range(n))
+    for pos in sorted(rng.choice(np.arange(3, n - 3), size=25, replace=False), reverse=True):
+        idx.insert(int(pos), 0xFFFF)
+    _px(gpu_device, [dict(verts=vv, indices=idx, topology=S)], w=128, h=64)
+
+
+def test_depth_ties_order_and_clip(gpu_device):
+    a = dict(verts=[(0, 0, .5), (0, 16, .5), (16, 0, .5)], indices=[0, 1, 2], debug_id=1)
+    b = dict(verts=[(0, 0, .5), (0, 16, .5), (16, 0, .5)], indices=[0, 1, 2], debug_id=2)
+    c = dict(verts=[(0, 0, .75), (0, 16, .75), (16, 0, .75)], indices=[0, 1, 2], debug_id=3)
+    _px(gpu_device, [a, b, c])
+    _px(gpu_device, [c, b, a])
+    _px(gpu_device, [dict(verts=[(0, 0, -0.5), (0, 32, -0.5), (64, 0, 1.5)], indices=[0, 1, 2])])
+    _px(gpu_device, [dict(verts=[(0, 0, 0.0), (0, 32, 1.0), (64, 0, 1.0)], indices=[0, 1, 2])])
+    _px(gpu_device, [a], clear=(0.1, 0.2, 0.3, 0.4), clear_depth=0.5)  # depth cleared to exactly the triangle's z
+
+
+def test_parts_disp_and_errors(gpu_device):
+    from mt_renderer_amd import api
+    a = dict(verts=[(0, 0, .5), (0, 8, .5), (8, 0, .5)], indices=[0, 1, 2], parts_no=1)
+    b = dict(verts=[(20, 0, .5), (20, 8, .5), (28, 0, .5)], indices=[0, 1, 2], parts_no=0)
+    _px(gpu_device, [a, b], parts_disp=[1, 0])
+    _px(gpu_device, [a, b], parts_disp=[0, 1])
+    md = pixel_model([dict(verts=[(0, 0, .5), (0, 8, .5), (8, 0, .5)], indices=[0, 1, 2], parts_no=5)])
+    with pytest.raises(api.MtrError) as e:
+        render_gpu(gpu_device, 64, 64, [dict(md=md, M=pixel_to_ndc_matrix(64, 64))])
+    assert e.value.code == api.MTR_E_INVALID
+    bad = scene.cube_model()
+    bad.layouts = [[(scene.SEM_POSITION, scene.IEF_U16, 2, 0)]]
+    with pytest.raises(api.MtrError) as e:
+        api.Model.new(gpu_device, bad)
+    assert e.value.code == api.MTR_E_UNSUPPORTED
+    with pytest.raises(api.MtrError) as e:
+        api.Texture.new(gpu_device, scene.TextureData(4, 4, 99, bytes(64)))
+    assert e.value.code == api.MTR_E_UNSUPPORTED
+    with pytest.raises(api.MtrError) as e:
+        api.Texture.new(gpu_device, scene.TextureData(8, 8, scene.TEX_BC7, bytes(16)))
+    assert e.value.code == api.MTR_E_INVALID
+
+
+def test_big_triangles_use_the_64bit_edge_path(gpu_device):
+    tris = [dict(verts=[(-3000.25, -2000.5, .2), (-1500, 9000.75, .9), (7000.5, -3000, .6)], indices=[0, 1, 2], debug_id=4),
+            dict(verts=[(-100000, 10, .5), (50, 90000, .5), (120000, -60000, .45)], indices=[0, 1, 2], debug_id=5),
+            dict(verts=[(-900000.0, -900000.0, .7), (-900000.0, 900000.0, .7), (900000.0, 0.0, .3)], indices=[0, 1, 2], debug_id=6),
+            dict(verts=[(10.5, 10.5, .1), (10.5, 100.25, .1), (100.75, 55.5, .1)], indices=[0, 1, 2], debug_id=7)]
+    _px(gpu_device, tris, w=256, h=128)
+    # beyond the guard band (2^20 px): dropped by both
+    _px(gpu_device, [dict(verts=[(-2e6, 0, .5), (0, 3e6, .5), (2e6, 0, .5)], indices=[0, 1, 2])], w=256, h=128)
+
+
+def test_near_plane_clip(gpu_device):
+    w, h = 320, 200
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=24, cols=36)
+    vp = scene.reference_view_proj(w, h)
+    for dz in (0.05, 0.2, 0.34, 0.5):  # the capsule straddles the near plane (z_eye = -0.01) / encloses the camera
+        M = scene.to_f32_colmajor(vp @ scene.mat_translate(-5.0, 0.05, 1.0 - dz) @ scene.mat_rot_x(0.7))
+        g = _both(gpu_device, w, h, [dict(md=md, M=M, palette=scene.bone_palette())])
+        assert g[2]["tris_setup"] > 0
+
+
+VERTEX_FORMATS = [
+    # (position element, texcoord element, stride): every float-class arm of src/rshader2.rs:516-564
+    ((scene.SEM_POSITION, scene.IEF_F32, 3, 0), (scene.SEM_TEXCOORD, scene.IEF_F16, 2, 12), 16),
+    ((scene.SEM_POSITION, scene.IEF_S16N, 3, 0), (scene.SEM_TEXCOORD, scene.IEF_U8N, 4, 8), 12),
+    ((scene.SEM_POSITION, scene.IEF_S16N, 1, 0), (scene.SEM_TEXCOORD, scene.IEF_S8N, 1, 4), 6),
+    ((scene.SEM_POSITION, scene.IEF_S8N, 3, 1), (scene.SEM_TEXCOORD, scene.IEF_U8N, 1, 5), 7),      # unaligned
+    ((scene.SEM_POSITION, scene.IEF_S8N, 4, 0), (scene.SEM_TEXCOORD, scene.IEF_U8NL, 3, 4), 8),
+    ((scene.SEM_POSITION, scene.IEF_F16, 2, 2), (scene.SEM_TEXCOORD, scene.IEF_S16N, 1, 6), 10),    # 2-byte aligned
+    ((scene.SEM_POSITION, scene.IEF_U8N, 4, 3), (scene.SEM_TEXCOORD, scene.IEF_F32, 3, 7), 19),     # unaligned F32
+    ((scene.SEM_POSITION, scene.IEF_F32, 3, 0), (scene.SEM_TEXCOORD, scene.IEF_S16N, 3, 12), 20),
+]
+
+
+@pytest.mark.parametrize("fmt", VERTEX_FORMATS, ids=lambda f: f"pos{f[0][1]}x{f[0][2]}_uv{f[1][1]}x{f[1][2]}_s{f[2]}")
+def test_vertex_formats(gpu_device, fmt):
+    pos_el, uv_el, stride = fmt
+    rng = np.random.default_rng(stride)
+    nv = 300
+    vb = rng.integers(0, 256, size=(nv, stride), dtype=np.uint8)
+    if pos_el[1] == scene.IEF_F32:
+        vb[:, 0:12] = rng.uniform(-0.9, 0.9, size=(nv, 3)).astype(np.float32).view(np.uint8).reshape(nv, 12)
+    if pos_el[1] == scene.IEF_F16:
+        vb[:, 2:6] = rng.uniform(-0.9, 0.9, size=(nv, 2)).astype("<f2").view(np.uint8).reshape(nv, 4)
+    if uv_el[1] == scene.IEF_F32:
+        vb[:, 7:19] = rng.uniform(0, 1, size=(nv, 3)).astype(np.float32).view(np.uint8).reshape(nv, 12)
+    if uv_el[1] == scene.IEF_F16:
+        vb[:, 12:16] = rng.uniform(0, 1, size=(nv, 2)).astype("<f2").view(np.uint8).reshape(nv, 4)
+    idx = rng.integers(0, nv, size=900).astype(np.uint16)
+    tex = scene.checker_rgba8_texture(32, 32, cell=4, alpha=(255, 120))
+    base = 3 if stride in (7, 19) else 0  # unaligned vertex_base as well
+    md = scene.ModelData(
+        vertex_buf=np.concatenate([np.zeros(base, np.uint8), vb.reshape(-1)]), index_buf=idx,
+        prims=scene.pack_primitive(vertex_num=nv, vertex_stride=stride, topology=scene.TOPO_LIST, index_num=len(idx),
+                                   vertex_base=base)[None, :],
+        layouts=[[pos_el, uv_el, (77, scene.IEF_F32, 3, 0), (scene.SEM_POSITION, scene.IEF_SCMP3N, 1, 0)][:3]],
+        prim_to_texture=np.array([0], np.int32), prim_debug_id=np.array([3], np.uint32), parts_disp=np.ones(1, np.uint8),
+        textures=[tex])
+    w, h = 160, 96
+    M = scene.to_f32_colmajor(scene.mat_translate(0.05, -0.03, 0.5) @ scene.mat_scale(0.9, 0.9, 0.4))
+    _both(gpu_device, w, h, [dict(md=md, M=M)])
+    # and the vertex stage alone, bit for bit
+    from mt_renderer_amd import api
+    m = api.Model.new(gpu_device, md)
+    try:
+        gc, gu = m.vertex_stage(0, M)
+    finally:
+        m.close()
+    oc, ou = orc.OracleModel(md).vertex_stage(0, M)
+    assert (gc.view(np.uint32) == oc.view(np.uint32)).all() and (gu.view(np.uint32) == ou.view(np.uint32)).all()
+
+
+def test_vertex_stage_skinned_bitwise(gpu_device):
+    from mt_renderer_amd import api
+    md = scene.skinned_capsule_model([((0.1, -0.2, 0.05), 0.3, 1.2)], rows=40, cols=60)
+    M = scene.to_f32_colmajor(scene.headline_transform(1920, 1080))
+    pal = scene.bone_palette(64, t=1.7)
+    m = api.Model.new(gpu_device, md)
+    try:
+        for p in (None, pal, pal[:5]):  # no palette / full / short palette (joint index clamped)
+            m.set_palette(p)
+            gc, gu = m.vertex_stage(0, M)
+            oc, ou = orc.OracleModel(md).vertex_stage(0, M, p)
+            assert (gc.view(np.uint32) == oc.view(np.uint32)).all() and (gu.view(np.uint32) == ou.view(np.uint32)).all()
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("kind", ["rgba8", "bc1", "bc7"])
+def test_texture_decode_parity(gpu_device, kind):
+    from mt_renderer_amd import api
+    for (w, h) in [(64, 64), (52, 36), (7, 5), (4, 4)]:
+        t = {"rgba8": scene.checker_rgba8_texture(w, h, 3, (255, 40)), "bc1": scene.random_bc1_texture(w, h, 9),
+             "bc7": scene.random_bc7_texture(w, h, 11)}[kind]
+        tex = api.Texture.new(gpu_device, t)
+        try:
+            got = tex.read_rgba8()
+        finally:
+            tex.close()
+        assert (got == orc.decode_texture(t.fmt, w, h, t.data)).all(), (kind, w, h)
+
+
+def test_textured_sampling_and_blending(gpu_device):
+    texs = [scene.checker_rgba8_texture(64, 64, cell=4), scene.random_bc7_texture(32, 32, 3),
+            scene.random_bc1_texture(16, 16, 4), scene.checker_rgba8_texture(4, 4, cell=1, alpha=(90, 200))]
+    prims = [_quad(0, 0, 8, 8, .5, tex=0),                       # minified -> nearest
+             _quad(10, 0, 74, 64, .5, tex=3),                    # magnified -> linear, translucent
+             _quad(0, 10, 40, 50, .6, tex=1), _quad(20, 30, 60, 60, .4, tex=1),   # BC7 with alpha, overlapping
+             _quad(30, 5, 62, 37, .45, tex=2, u0=-0.5, v0=-0.25, u1=1.5, v1=1.25),  # BC1, uv outside [0,1] -> clamp
+             _quad(5, 40, 30, 63, .3, tex=-1, did=9)]             # untextured among textured
+    _px(gpu_device, prims, w=80, h=64, textures=texs)
+    # rho right at the mag/min switch: one texel per pixel, and slightly more / less
+    for scale in (1.0, 1.0000001, 0.9999999, 1.5, 0.75):
+        _px(gpu_device, [_quad(0, 0, 32, 32, .5, u1=scale, v1=scale, tex=0)], w=32, h=32,
+            textures=[scene.checker_rgba8_texture(32, 32, cell=1, alpha=(255, 77))])
+
+
+def test_textured_perspective_skinned(gpu_device):
+    w, h = 640, 360
+    tex = scene.random_bc7_texture(128, 128, seed=21)
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=30, cols=48, textured=True, textures=[tex])
+    M = scene.to_f32_colmajor(scene.headline_transform(w, h))
+    _both(gpu_device, w, h, [dict(md=md, M=M, palette=scene.bone_palette())])
+    # close-up: magnified, perspective-correct texcoords, near-plane clipping of textured triangles
+    vp = scene.reference_view_proj(w, h)
+    M2 = scene.to_f32_colmajor(vp @ scene.mat_translate(-5.0, 0.0, 1.0 - 0.3) @ scene.mat_rot_x(0.5))
+    _both(gpu_device, w, h, [dict(md=md, M=M2, palette=scene.bone_palette())])
+
+
+def test_instances_batches_and_draw_order(gpu_device):
+    w, h = 480, 270
+    texs = [scene.checker_rgba8_texture(16, 16, 2, (255, 128)), scene.random_bc7_texture(16, 16, 8)]
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=16, cols=20, textured=True, textures=texs)
+    mats, pals = scene.instance_lattice(4, 3)
+    vp = scene.to_f32_colmajor(scene.reference_view_proj(w, h))
+    cube = scene.cube_model(6)
+    Mc = scene.to_f32_colmajor(scene.reference_view_proj(w, h) @ scene.mat_translate(-5, 0, -1.2) @ scene.mat_scale(.6, .6, .6))
+    draws = [dict(md=cube, M=Mc),
+             dict(md=md, vp=vp, model_mats=mats, palettes=pals, tex_override=[0, 1, -1, 1, 0, 0, 1, 1, -1, 0, 1, 0]),
+             dict(md=md, vp=vp, model_mats=mats[:5] @ np.eye(16, dtype=np.float32), palettes=None),
+             dict(md=cube, M=Mc)]
+    g = _both(gpu_device, w, h, draws)
+    assert g[2]["ndraws"] == 4
+
+
+def test_debug_overlay_cubes(gpu_device):
+    w, h = 256, 256
+    cam = scene.to_f32_colmajor(scene.reference_view_proj(w, h))
+    inst = np.stack([scene.to_f32_colmajor(scene.mat_translate(-5 + 0.3 * i - 0.6, 0.2 * (i % 3) - 0.2, -1.0 - 0.1 * i) @
+                                          scene.mat_scale(0.1, 0.1, 0.1) @ scene.mat_rot_y(0.3 * i)) for i in range(7)])
+    md = scene.cube_model(2)
+    M = scene.to_f32_colmajor(scene.cube_transform(w, h))
+    _both(gpu_device, w, h, [dict(md=md, M=M), dict(md=md, vp=cam, overlay=inst)])
+
+
+def test_many_segments_in_one_bin(gpu_device):
+    """1200 translucent quads (one strip each, 0xFFFF-separated) stacked at equal depth inside a couple of
+    16x16 bins: ~100 geometry chunks feed each bin, far more than the 64 segments the tile kernel sorts per
+    key range, and every fragment blends, so any ordering slip changes the colour."""
+    rng = np.random.default_rng(42)
+    nq = 1200
+    verts, idx = [], []
+    for q in range(nq):
+        x0, y0 = rng.uniform(1, 26), rng.uniform(1, 12)
+        sz = rng.uniform(1.5, 4.0)
+        u, v = rng.uniform(0, 1, 2)
+        b = 4 * q
+        verts += [(x0, y0, .5, u, v), (x0, y0 + sz, .5, u, v), (x0 + sz, y0, .5, u, v), (x0 + sz, y0 + sz, .5, u, v)]
+        idx += [b, b + 1, b + 2, b + 3, 0xFFFF]
+    tex_img = rng.integers(0, 256, size=(32, 32, 4), dtype=np.uint8)
+    tex_img[..., 3] = rng.integers(60, 200, size=(32, 32))
+    tex = scene.TextureData(32, 32, scene.TEX_RGBA8, tex_img.tobytes())
+    g = _px(gpu_device, [dict(verts=verts, indices=idx, topology=scene.TOPO_STRIP, texture=0)], w=64, h=32, textures=[tex])
+    assert g[2]["tris_setup"] == 2 * nq and g[2]["segments"] > 2 * 64 + 20, g[2]
+
+
+def test_sharded_bins_and_pack_unpack(gpu_device):
+    import torch
+    from mt_renderer_amd import api
+    w, h = 333, 171
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=24, cols=36)
+    M = scene.to_f32_colmajor(scene.headline_transform(w, h))
+    draws = [dict(md=md, M=M, palette=scene.bone_palette())]
+    full = render_oracle(w, h, draws)
+    for world in (2, 3, 8):
+        shards = []
+        for rank in range(world):
+            m = api.Model.new(gpu_device, md)
+            m.set_palette(scene.bone_palette())
+            fr = api.Frame(gpu_device, w, h)
+            fr.set_shard(rank, world)
+            m.render(fr, M)
+            fr.end()
+            own = sharding.owner_map(w, h, world) == rank
+            c, d = fr.color(), fr.depth()
+            assert (c[own] == full[0][own]).all() and (d[own] == full[1][own]).all()
+            buf = torch.zeros(sharding.shard_bytes(w, h, world), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # torch's stream and the library's stream are different streams
+            fr.pack_color_shard(buf.data_ptr(), buf.numel())
+            fr.wait()
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().reshape(-1, sharding.BIN, sharding.BIN, 4)
+            mine = np.where(own[..., None], c, 0).astype(np.uint8)
+            assert (got == sharding.pack_shard(mine, rank, world)).all()
+            shards.append(buf)
+            fr.close()
+            m.close()
+        gathered = torch.cat(shards)
+        out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        gpu_device.unpack_color_shards(gathered.data_ptr(), world, w, h, out.data_ptr())
+        # the unpack runs on the library's stream
+        fr = api.Frame(gpu_device, 16, 16)
+        fr.end()
+        fr.close()
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy().reshape(h, w, 4) == full[0]).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_clip_space_soup(gpu_device, seed):
+    """Seeded fuzz: random triangles straight in clip space through a random perspective-like matrix --
+    negative / zero w, z outside the volume, sub-pixel slivers, huge extents."""
+    rng = np.random.default_rng(seed)
+    nv, nt = 120, 200
+    v = rng.normal(0, 1.2, size=(nv, 3)).astype(np.float32)
+    v[rng.integers(0, nv, 10)] *= 50.0
+    idx = rng.integers(0, nv, size=3 * nt).astype(np.uint16)
+    md = scene.ModelData(
+        vertex_buf=v.view(np.uint8).reshape(-1).copy(), index_buf=idx,
+        prims=scene.pack_primitive(vertex_num=nv, vertex_stride=12, topology=scene.TOPO_LIST, index_num=len(idx))[None, :],
+        layouts=[[(scene.SEM_POSITION, scene.IEF_F32, 3, 0)]], prim_to_texture=np.array([-1], np.int32),
+        prim_debug_id=np.array([seed], np.uint32), parts_disp=np.ones(1, np.uint8))
+    M = rng.normal(0, 1, size=(4, 4))
+    M[3] = (0.1 * rng.normal(), 0.1 * rng.normal(), -1.0, 0.8)  # w depends on z: some vertices behind the eye
+    _both(gpu_device, 200, 120, [dict(md=md, M=scene.to_f32_colmajor(M))])
