@@ -1,0 +1,122 @@
+// mtr.hpp -- C++ host mirror of the reference's GPU-object layer over the C ABI (mtr.h).
+// Same names and argument roles as mt-renderer's Rust API: Texture::new (src/texture.rs:11),
+// Model::new / set_parts_disp / render (src/model.rs:36-45, :295, :299-305); wgpu::Device+Queue -> mtr::Device,
+// wgpu::RenderPass -> mtr::Frame.  Errors (the reference's anyhow::Result / panics) become mtr::Error.
+#pragma once
+#include "mtr.h"
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace mtr {
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string& m) : std::runtime_error("mtr error " + std::to_string(c) + ": " + m), code(c) {}
+};
+
+class Device {
+  public:
+    explicit Device(int hip_device = 0) {
+        int32_t rc = mtr_device_create(hip_device, &h_);
+        if (rc) throw Error(rc, mtr_last_error(nullptr));
+    }
+    Device(const Device&) = delete;
+    Device& operator=(const Device&) = delete;
+    ~Device() { mtr_device_destroy(h_); }
+    mtr_device* handle() const { return h_; }
+    void check(int32_t rc) const {
+        if (rc) throw Error(rc, mtr_last_error(h_));
+    }
+
+  private:
+    mtr_device* h_ = nullptr;
+};
+
+class Texture {
+  public:
+    // Texture::new(device, queue, resource) -- src/texture.rs:11
+    Texture(const Device& dev, uint32_t width, uint32_t height, uint32_t format, const void* data, size_t len) {
+        dev.check(mtr_texture_create(dev.handle(), width, height, format, data, len, &h_));
+    }
+    Texture(Texture&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    Texture(const Texture&) = delete;
+    ~Texture() { mtr_texture_destroy(h_); }
+    mtr_texture* handle() const { return h_; }
+
+  private:
+    mtr_texture* h_ = nullptr;
+};
+
+class Frame;
+
+class Model {
+  public:
+    // Model::new(model_file, material_file, shader2, resource_manager, device, queue, ..) -- src/model.rs:36-45
+    Model(const Device& dev, const void* vertex_buf, size_t vertex_len, const uint16_t* index_buf, size_t index_num,
+          const std::vector<mtr_primitive>& prims, const std::vector<mtr_layout>& layouts,
+          const std::vector<int32_t>& prim_to_texture, const std::vector<const Texture*>& textures,
+          const std::vector<uint32_t>& prim_debug_id)
+        : dev_(dev) {
+        if (layouts.size() != prims.size() || prim_to_texture.size() != prims.size() || prim_debug_id.size() != prims.size())
+            throw Error(MTR_E_INVALID, "per-primitive arrays must have one entry per primitive");
+        std::vector<mtr_texture*> th;
+        for (const Texture* t : textures) th.push_back(t->handle());
+        dev.check(mtr_model_create(dev.handle(), vertex_buf, vertex_len, index_buf, index_num, prims.data(), prims.size(),
+                                   layouts.data(), prim_to_texture.data(), th.data(), th.size(), prim_debug_id.data(), &h_));
+    }
+    Model(const Model&) = delete;
+    ~Model() { mtr_model_destroy(h_); }
+    // Model::set_parts_disp(&mut self, parts_disp: &[bool]) -- src/model.rs:295
+    void set_parts_disp(const std::vector<uint8_t>& parts_disp) {
+        dev_.check(mtr_model_set_parts_disp(h_, parts_disp.data(), parts_disp.size()));
+    }
+    void set_palette(const float* mats, size_t n) { dev_.check(mtr_model_set_palette(h_, mats, n)); }
+    // Model::render(&self, rpass, queue, transform_bind_group, debug_overlay) -- src/model.rs:299-305
+    void render(Frame& frame, const float view_proj[16]) const;
+    mtr_model* handle() const { return h_; }
+
+  private:
+    const Device& dev_;
+    mtr_model* h_ = nullptr;
+};
+
+class Frame {
+  public:
+    // begin_render_pass, LoadOp::Clear(WHITE) / Clear(1.0) -- src/bin/modelviewer.rs:190-210
+    Frame(const Device& dev, uint32_t width, uint32_t height, const float clear_rgba[4], float clear_depth) : dev_(dev) {
+        dev.check(mtr_frame_begin(dev.handle(), width, height, clear_rgba, clear_depth, &h_));
+    }
+    Frame(const Frame&) = delete;
+    ~Frame() { mtr_frame_destroy(h_); }
+    void end() { dev_.check(mtr_frame_end(h_)); }  // queue.submit, src/renderer_app_manager.rs:185
+    void read_color(void* rgba8, size_t len) { dev_.check(mtr_frame_read_color(h_, rgba8, len)); }
+    void read_depth(float* d, size_t count) { dev_.check(mtr_frame_read_depth(h_, d, count)); }
+    mtr_frame_stats stats() {
+        mtr_frame_stats s{};
+        dev_.check(mtr_frame_get_stats(h_, &s));
+        return s;
+    }
+    mtr_frame* handle() const { return h_; }
+    const Device& device() const { return dev_; }
+
+  private:
+    const Device& dev_;
+    mtr_frame* h_ = nullptr;
+};
+
+inline void Model::render(Frame& frame, const float view_proj[16]) const {
+    dev_.check(mtr_frame_draw_model(frame.handle(), h_, view_proj));
+}
+
+// The reference's app seam (src/renderer_app_manager.rs:14-32), headless: the "frame_view + encoder" pair is the Frame.
+struct RendererApp {
+    virtual ~RendererApp() = default;
+    virtual void render(Frame& frame) = 0;
+    virtual void post_render() {}
+};
+
+}  // namespace mtr

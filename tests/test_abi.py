@@ -79,3 +79,28 @@ def test_product_does_not_touch_the_oracle():
                     if re.search(r"(from|import)\s+oracle\b|oracle/|mtr_oracle|liboracle", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def _build_cpp_demo(td):
+    exe = os.path.join(td, "cube_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "cube_demo.cpp"), "-o", exe,
+                           "-L", os.path.join(ROOT, "mt_renderer_amd"), "-lmtr", "-Wl,-rpath," + os.path.join(ROOT, "mt_renderer_amd")])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_fails_loudly_without_gpu():
+    import torch
+    with tempfile.TemporaryDirectory() as td:
+        exe = _build_cpp_demo(td)
+        if torch.cuda.is_available():
+            pytest.skip("GPU present: covered by the gpu-marked test")
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 77, (r.returncode, r.stderr)  # MTR_E_HIP surfaced as mtr::Error
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_renders_the_cube():
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([_build_cpp_demo(td)], capture_output=True, text=True)
+        assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
