@@ -81,6 +81,8 @@ typedef struct mtr_frame_stats {
     uint64_t bin_entries; /* (triangle, 32x32 bin) pairs */
     uint64_t segments;    /* per-bin ordered runs */
     uint32_t width, height, nbins, ndraws;
+    uint32_t tile_kernel; /* MTR_TILE_ORDERED or MTR_TILE_VISIBILITY: which tile kernel rendered the frame */
+    uint32_t pad;
 } mtr_frame_stats;
 
 /* stage timings of the last submitted frame, milliseconds, from hipEvents recorded on the
@@ -94,6 +96,11 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void *hip_stream, mtr_de
 void mtr_device_destroy(mtr_device *dev);
 const char *mtr_last_error(const mtr_device *dev); /* never NULL; dev may be NULL for create errors */
 int32_t mtr_device_set_profiling(mtr_device *dev, int32_t enable);
+/* tile-kernel choice.  AUTO: the visibility-key kernel when every material of the frame is opaque (debug-id /
+ * overlay colours, textures whose alpha is 255 everywhere -- the blend is then a replace), else the ordered
+ * kernel.  ORDERED forces the ordered kernel (tests compare both); VISIBILITY is honoured only when eligible. */
+enum { MTR_TILE_AUTO = 0, MTR_TILE_ORDERED = 1, MTR_TILE_VISIBILITY = 2 };
+int32_t mtr_device_set_tile_mode(mtr_device *dev, int32_t mode);
 int32_t mtr_abi_version(void);
 
 /* ---- Texture::new (src/texture.rs:11-30): level 0 only, 2-D, decoded on upload ---- */
@@ -160,6 +167,9 @@ int32_t mtr_device_unpack_color_shards(mtr_device *dev, const void *gathered_dev
                                        uint32_t width, uint32_t height, void *dst_dev);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
+/* tuning / test hook: per-bin queue sizes of the frame just rendered (valid until the next frame is submitted on
+ * this device): entries[b] = (triangle, bin) pairs of 16x16 bin b, segments[b] = ordered runs; nbins each */
+int32_t mtr_frame_read_bin_counts(mtr_frame *frame, uint32_t *entries, uint32_t *segments, size_t nbins);
 void mtr_frame_destroy(mtr_frame *frame);
 
 /* ---- unit-test hooks: one stage at a time through the same kernels ---- */

@@ -20,6 +20,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmtr.so")
 
 MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
+TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY = 0, 1, 2
 STAGE_NAMES = ("geom", "scan", "fill", "tile")
 
 # every symbol include/mtr.h declares (tests check that the library exports each one)
@@ -32,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mtr_frame_wait", "mtr_frame_end", "mtr_frame_read_color", "mtr_frame_read_depth", "mtr_frame_color_devptr",
     "mtr_frame_depth_devptr", "mtr_frame_get_stats", "mtr_frame_get_timings", "mtr_frame_destroy",
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
-    "mtr_device_unpack_color_shards",
+    "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode",
 ]
 
 
@@ -58,7 +59,7 @@ class _Layout(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
                 ("segments", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("nbins", C.c_uint32),
-                ("ndraws", C.c_uint32)]
+                ("ndraws", C.c_uint32), ("tile_kernel", C.c_uint32), ("pad", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -107,6 +108,8 @@ def _load() -> C.CDLL:
         "mtr_shard_bytes": (sz, [u32, u32, u32]),
         "mtr_frame_pack_color_shard": (i32, [vp, vp, sz]),
         "mtr_device_unpack_color_shards": (i32, [vp, vp, u32, u32, u32, vp]),
+        "mtr_frame_read_bin_counts": (i32, [vp, vp, vp, sz]),
+        "mtr_device_set_tile_mode": (i32, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -150,6 +153,10 @@ class Device:
         """gathered [rank][k][16][16] RGBA8 blocks (device) -> linear RGBA8 framebuffer (device)."""
         self.check(lib.mtr_device_unpack_color_shards(self._h, C.c_void_p(gathered_devptr), world, width, height,
                                                       C.c_void_p(dst_devptr)))
+
+    def set_tile_mode(self, mode: int):
+        """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""
+        self.check(lib.mtr_device_set_tile_mode(self._h, mode))
 
     def set_profiling(self, on: bool):
         self.check(lib.mtr_device_set_profiling(self._h, 1 if on else 0))
@@ -346,6 +353,14 @@ class Frame:
         s = FrameStats()
         self.dev.check(lib.mtr_frame_get_stats(self._h, C.byref(s)))
         return s.as_dict()
+
+    def bin_counts(self):
+        """(entries, segments) per 16x16 bin of the frame just rendered (tuning / test hook)."""
+        n = self.stats()["nbins"]
+        e = np.zeros(n, dtype=np.uint32)
+        s = np.zeros(n, dtype=np.uint32)
+        self.dev.check(lib.mtr_frame_read_bin_counts(self._h, _p(e), _p(s), n))
+        return e, s
 
     def timings_ms(self) -> dict:
         ms = (C.c_float * 4)()

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_fill(FrameBuffers fb, uint32_t total_ch
             const uint32_t thi = __builtin_amdgcn_readlane((uint32_t)(t >> 32), leader);
             if (hit) {
                 const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                fb.entries[fb.bin_start[bin] + tlo + rank] = ci.base + j;
+                fb.entries[fb.bin_start[bin] + tlo + rank] = make_uint2(ci.base + j, gid * 128u + j);
                 if (lane == leader) {
                     Seg sg = {gid * 2u + round, tlo, cnt, 0u};
                     fb.segs[fb.seg_start[bin] + thi] = sg;

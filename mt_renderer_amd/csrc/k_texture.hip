@@ -175,7 +175,21 @@ __global__ __launch_bounds__(64) void k_bc7_decode(const uint8_t* blocks, uint8_
     store_block(rgba, w, h, b % bw, b / bw, px);
 }
 
+// minimum alpha over a decoded RGBA8 texture (Texture::new time): 255 <=> the texture is opaque
+__global__ __launch_bounds__(256) void k_alpha_min(const uint32_t* rgba, size_t n, uint32_t* out) {
+    uint32_t mn = 255;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) mn = min(mn, rgba[i] >> 24);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, d));
+    if ((threadIdx.x & 63) == 0 && mn != 255) atomicMin(out, mn);
+}
+
 }  // namespace mtr
+
+void mtr_launch_alpha_min(const uint8_t* rgba, size_t npixels, uint32_t* out_min, hipStream_t s) {
+    const uint32_t grid = (uint32_t)((npixels + 255) / 256 < 1024 ? (npixels + 255) / 256 : 1024);
+    hipLaunchKernelGGL(mtr::k_alpha_min, dim3(grid ? grid : 1), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(rgba), npixels, out_min);
+}
 
 void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s) {
     const uint32_t nb = ((w + 3) / 4) * ((h + 3) / 4);

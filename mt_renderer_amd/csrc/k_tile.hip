@@ -14,7 +14,7 @@
 //      src/shaders/textured.wgsl + sampler src/texture.rs:33-42) and the blend
 //      (src/model.rs:240-247) in submission order,
 //   4. colour + depth leave the CU once (clear is fused: no separate clear pass).
-#include "mtr_internal.h"
+#include "tile_common.h"
 
 namespace mtr {
 
@@ -45,75 +45,6 @@ struct TriX {
 };
 static_assert(sizeof(TriC) == 64 && sizeof(TriX) == 64, "LDS triangle records are 64 B");
 enum { TF_LARGE = 1, TF_TEX = 2, TF_BLEND = 4 };
-
-__device__ __forceinline__ float unorm8f(uint32_t v) { return (float)(v & 0xffu) / 255.0f; }
-__device__ __forceinline__ uint32_t quant8(float x) {
-    if (!(x > 0.0f)) x = 0.0f;
-    if (x > 1.0f) x = 1.0f;
-    return (uint32_t)rintf(x * 255.0f);
-}
-__device__ __forceinline__ int32_t clamp_texel(float f, uint32_t n) {
-    if (!(f >= 0.0f)) f = 0.0f;
-    if (f > (float)(n - 1)) f = (float)(n - 1);
-    return (int32_t)f;
-}
-struct TexRef {
-    const uint8_t* tex;
-    uint32_t tw, th;
-};
-__device__ __forceinline__ void texel_f(const TexRef& m, int32_t x, int32_t y, float (&o)[4]) {
-    uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[(size_t)y * m.tw + (size_t)x];
-    o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
-}
-
-// textureSample: clamp-to-edge, mag linear / min nearest, one level (src/texture.rs:21,33-42).
-// du/dx etc. are fine quad differences of the per-lane (u,v): SPEC.md "sampling".
-__device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v, bool linear, float (&o)[4]) {
-    const float fw = (float)m.tw, fh = (float)m.th;
-    if (!linear) {
-        texel_f(m, clamp_texel(floorf(u * fw), m.tw), clamp_texel(floorf(v * fh), m.th), o);
-        return;
-    }
-    float x = u * fw - 0.5f, y = v * fh - 0.5f;
-    float x0 = floorf(x), y0 = floorf(y);
-    float fx = x - x0, fy = y - y0;
-    int32_t ix0 = clamp_texel(x0, m.tw), ix1 = clamp_texel(x0 + 1.0f, m.tw);
-    int32_t iy0 = clamp_texel(y0, m.th), iy1 = clamp_texel(y0 + 1.0f, m.th);
-    float c00[4], c10[4], c01[4], c11[4];
-    texel_f(m, ix0, iy0, c00); texel_f(m, ix1, iy0, c10); texel_f(m, ix0, iy1, c01); texel_f(m, ix1, iy1, c11);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float top = fmaf(fx, c10[c] - c00[c], c00[c]);
-        float bot = fmaf(fx, c11[c] - c01[c], c01[c]);
-        o[c] = fmaf(fy, bot - top, top);
-    }
-}
-
-__device__ __forceinline__ uint32_t blend_store(uint32_t dst, const float (&src)[4], bool blend) {
-    uint32_t out = 0;
-    if (blend) {
-        const float a = src[3], ia = 1.0f - a;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            float d = unorm8f(dst >> (8 * c));
-            float t = d * ia;
-            out |= quant8(fmaf(src[c], a, t)) << (8 * c);
-        }
-        out |= quant8(src[3]) << 24;
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; c++) out |= quant8(src[c]) << (8 * c);
-    }
-    return out;
-}
-
-// LDS traffic between lanes of ONE wave: ds operations of a wave complete in order; this only stops
-// the compiler from moving accesses across the hand-off point.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // per-entry set-up by one lane: record -> bin-relative edge equations in LDS
 template <bool TEX>
@@ -281,7 +212,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                         const uint32_t mid = (a + b) >> 1;
                         if (s_pre[mid] <= e) a = mid; else b = mid;
                     }
-                    const uint32_t r = P.fb.entries[ent_lo + s_off[a] + (e - s_pre[a])];
+                    const uint32_t r = P.fb.entries[ent_lo + s_off[a] + (e - s_pre[a])].x;
                     setup_entry<TEX>(P, r, binx0, biny0, s_tc[lane], TEX ? &s_tx[lane] : nullptr, s_chi[lane], s_mask[lane]);
                 }
                 wave_lds_sync();

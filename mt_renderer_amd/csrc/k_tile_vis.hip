@@ -1,0 +1,278 @@
+// k_tile_vis.hip -- visibility-key tile kernel for frames whose every material is opaque
+// (debug-id / overlay colours, or textures with alpha == 255 everywhere: blend = replace).
+//
+// For such frames the per-pixel result of the ordered pipeline (depth LessEqual + write, blend with
+// a = 1) is a pure reduction: the winner of a pixel is the fragment with the smallest z, the LATEST
+// in submission order among equals.  So each pixel keeps one 64-bit key  (~bits(z) : order+1)  in
+// LDS and every fragment is an order-independent, fire-and-forget `ds_max_u64`:
+//   * 64 triangles are set up per pass, one per lane, into LDS;
+//   * their (triangle, pixel-of-bbox) pairs are FLATTENED over the wave with a prefix sum (wave
+//     shuffles) + binary search, so a pass costs sum(bbox pixels)/64 iterations whatever the mix of
+//     1-pixel slivers and bin-filling triangles -- instead of a whole wave per (triangle, sub-tile)
+//     as in the ordered kernel;
+//   * shading is deferred: the winner's record is addressable from its order (chunk runs live at
+//     chunk * MTR_CHUNK_SLOTS), so the resolve does one colour lookup -- or one texture sample with the
+//     quad derivatives evaluated from the winner's plane equations exactly as SPEC.md section 7
+//     defines them -- per pixel, then the only framebuffer write of the frame.
+// Same arithmetic per fragment as k_tile.hip, bit for bit; the host picks this kernel only when the
+// frame is eligible (mtr_api.cpp); tests run both kernels on the same scenes.
+// One wave per 16x16 bin, no workgroup barriers, no segment sort (order rides in the entry).
+#include "tile_common.h"
+
+namespace mtr {
+
+// LDS triangle record of one pass (64 B): everything a (triangle, pixel) work item needs
+struct VisTri {
+    int32_t A0, B0, C0, A1;  // edge i: E_i(lx,ly) = C_i + A_i*lx + B_i*ly, top-left bias folded into C_i
+    int32_t B1, C1, A2, B2;  // small class: i32, A/B pre-scaled by 256; large class: unscaled, C high words in s_chi
+    int32_t C2;
+    uint32_t flags;          // bit0 large, bits 4..6: 1 - tl_i
+    float z0, dz1;
+    float dz2, rcpA;
+    uint32_t ordk;           // submission order + 1
+    uint32_t box;            // px0 | py0 << 4 | (bw-1) << 8 | magic(bw) << 12   (k / bw = k * magic >> 16)
+};
+static_assert(sizeof(VisTri) == 64, "VisTri is 64 B");
+
+struct Setup {
+    VisTri t;
+    int4 chi;
+    int32_t npx;
+};
+
+__device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t binx0, int32_t biny0, Setup& s) {
+    const int32_t xmin = min(a.X0, min(a.X1, a.X2)), xmax = max(a.X0, max(a.X1, a.X2));
+    const int32_t ymin = min(a.Y0, min(a.Y1, a.Y2)), ymax = max(a.Y0, max(a.Y1, a.Y2));
+    const bool large = (xmax - xmin) > 16384 || (ymax - ymin) > 16384;
+    const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
+    int32_t A[3], B[3], Clo[3], Chi[3] = {0, 0, 0};
+    uint32_t flags = large ? 1u : 0u;
+    float fA2;
+    if (!large) {
+        // the bin overlaps the bbox, so every operand is < 2^16 and every product < 2^31: 24-bit multiplies
+        const int32_t Px = binx0 * 256 + 128, Py = biny0 * 256 + 128;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int ia = (i + 1) % 3, ib = (i + 2) % 3;
+            const int32_t dx = X[ib] - X[ia], dy = Y[ib] - Y[ia];
+            const int32_t tl = (dy > 0 || (dy == 0 && dx < 0)) ? 1 : 0;
+            flags |= (uint32_t)(1 - tl) << (4 + i);
+            A[i] = dy * 256; B[i] = -dx * 256;
+            Clo[i] = __mul24(dy, Px - X[ia]) - __mul24(dx, Py - Y[ia]) + (tl - 1);
+        }
+        fA2 = (float)(__mul24(X[2] - X[0], Y[1] - Y[0]) - __mul24(X[1] - X[0], Y[2] - Y[0]));
+    } else {
+        const long long Px = (long long)binx0 * 256 + 128, Py = (long long)biny0 * 256 + 128;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int ia = (i + 1) % 3, ib = (i + 2) % 3;
+            const int32_t dx = X[ib] - X[ia], dy = Y[ib] - Y[ia];
+            const int32_t tl = (dy > 0 || (dy == 0 && dx < 0)) ? 1 : 0;
+            const long long C = (long long)dy * (Px - X[ia]) - (long long)dx * (Py - Y[ia]) + (tl - 1);
+            flags |= (uint32_t)(1 - tl) << (4 + i);
+            A[i] = dy; B[i] = -dx;
+            Clo[i] = (int32_t)(uint32_t)(unsigned long long)C;
+            Chi[i] = (int32_t)(C >> 32);
+        }
+        fA2 = (float)((long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]));
+    }
+    const int32_t px0 = max(((xmin + 127) >> 8) - binx0, 0), px1 = min(((xmax - 128) >> 8) - binx0, MTR_BIN - 1);
+    const int32_t py0 = max(((ymin + 127) >> 8) - biny0, 0), py1 = min(((ymax - 128) >> 8) - biny0, MTR_BIN - 1);
+    const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
+    s.npx = (bw > 0 && bh > 0) ? bw * bh : 0;
+    const uint32_t ubw = (uint32_t)max(bw, 1);
+    const uint32_t magic = (65536u + ubw - 1u) / ubw;  // exact k / bw for k < 256, bw <= 16
+    s.t.A0 = A[0]; s.t.B0 = B[0]; s.t.C0 = Clo[0];
+    s.t.A1 = A[1]; s.t.B1 = B[1]; s.t.C1 = Clo[1];
+    s.t.A2 = A[2]; s.t.B2 = B[2]; s.t.C2 = Clo[2];
+    s.t.flags = flags;
+    s.t.z0 = a.z0; s.t.dz1 = a.z1 - a.z0; s.t.dz2 = a.z2 - a.z0;
+    s.t.rcpA = 1.0f / fA2;
+    s.t.ordk = ord + 1u;
+    s.t.box = (uint32_t)(px0 & 15) | ((uint32_t)(py0 & 15) << 4) | ((uint32_t)((bw - 1) & 15) << 8) | (magic << 12);
+    s.chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float z, uint32_t ordk) {
+    // 0 <= z <= 1 and z is never -0 (SPEC.md: vertex z comes from an fma chain started at +0), so the bit
+    // pattern is monotonic; larger key = nearer, then later
+    return ((unsigned long long)(~__float_as_uint(z)) << 32) | ordk;
+}
+
+// deferred textured shading of the winner at pixel (px,py): SPEC.md section 7, same operations as the
+// per-fragment path (the quad neighbours are evaluated from the same triangle's plane equations)
+__device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b, const DMat& mat, int32_t px, int32_t py) {
+    const long long A2 = (long long)(a.X2 - a.X0) * (long long)(a.Y1 - a.Y0) - (long long)(a.X1 - a.X0) * (long long)(a.Y2 - a.Y0);
+    const float rcpA = 1.0f / (float)A2;
+    const float diw1 = b.iw1 - b.iw0, diw2 = b.iw2 - b.iw0, dup1 = b.up1 - b.up0, dup2 = b.up2 - b.up0,
+                dvp1 = b.vp1 - b.vp0, dvp2 = b.vp2 - b.vp0;
+    auto uv_at = [&](int32_t qx, int32_t qy, float& u, float& v) {
+        const long long Px = (long long)qx * 256 + 128, Py = (long long)qy * 256 + 128;
+        const long long E1 = (long long)(a.Y0 - a.Y2) * (Px - a.X2) - (long long)(a.X0 - a.X2) * (Py - a.Y2);
+        const long long E2 = (long long)(a.Y1 - a.Y0) * (Px - a.X0) - (long long)(a.X1 - a.X0) * (Py - a.Y0);
+        const float b1 = (float)E1 * rcpA, b2 = (float)E2 * rcpA;
+        const float iw = fmaf(b2, diw2, fmaf(b1, diw1, b.iw0));
+        const float up = fmaf(b2, dup2, fmaf(b1, dup1, b.up0));
+        const float vp = fmaf(b2, dvp2, fmaf(b1, dvp1, b.vp0));
+        u = up / iw;
+        v = vp / iw;
+    };
+    float u, v, ua, va, ub, vb;
+    uv_at(px, py, u, v);
+    const int32_t qx = px & ~1, qy = py & ~1;
+    uv_at(qx, py, ua, va);
+    uv_at(qx + 1, py, ub, vb);
+    const float dudx = ub - ua, dvdx = vb - va;
+    uv_at(px, qy, ua, va);
+    uv_at(px, qy + 1, ub, vb);
+    const float dudy = ub - ua, dvdy = vb - va;
+    const TexRef tr = {mat.tex, mat.tw, mat.th};
+    float src[4];
+    sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, mat.tw, mat.th), src);
+    return blend_store(0u, src, false);  // opaque texture: a == 1 exactly, so the blend is a replace
+}
+
+template <bool TEX>
+__global__ __launch_bounds__(64) void k_tile_vis(TileParams P) {
+    __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
+    __shared__ __align__(16) VisTri s_tri[64];
+    __shared__ __align__(16) int4 s_chi[64];
+    __shared__ uint32_t s_pre[65];
+
+    const uint32_t lane = threadIdx.x;
+    uint32_t bin;
+    if (!block_to_bin(P.fb, bin)) return;
+    const uint32_t nbx = P.fb.nbx;
+    const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
+    const float cd = P.clear_depth;
+    const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_key[lane + 64 * i] = 0ull;
+
+    const uint32_t ent_lo = P.fb.bin_start[bin], N = P.fb.bin_start[bin + 1] - ent_lo;
+    const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
+    // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
+    // record loads of pass k+1 and the entry loads of pass k+2 are in flight.  The record of an entry is
+    // addressable from its submission order: chunk run base = chunk * MTR_CHUNK_SLOTS.
+    uint32_t ord_cur = 0, ord_nxt = 0;
+    if (lane < N) ord_cur = P.fb.entries[ent_lo + lane].y;
+    if (64 + lane < N) ord_nxt = P.fb.entries[ent_lo + 64 + lane].y;
+    RecA a_cur = zero_rec;
+    if (lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
+    for (uint32_t e0 = 0; e0 < N; e0 += 64) {
+        const bool valid = e0 + lane < N;
+        RecA a_nxt = zero_rec;
+        if (e0 + 64 + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
+        uint32_t ord_nn = 0;
+        if (e0 + 128 + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 128 + lane].y;
+
+        Setup s;
+        s.npx = 0;
+        if (valid) {
+            setup_tri(a_cur, ord_cur, binx0, biny0, s);
+            s_tri[lane] = s.t;
+            s_chi[lane] = s.chi;
+        }
+        // exclusive prefix of the per-triangle pixel counts
+        uint32_t inc = (uint32_t)s.npx;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
+            if ((int)lane >= d) inc += t;
+        }
+        s_pre[lane] = inc - (uint32_t)s.npx;
+        if (lane == 63) s_pre[64] = inc;
+        wave_lds_sync();
+        const uint32_t T = s_pre[64];
+
+        // ---- flattened (triangle, pixel) work items: item w belongs to triangle j with pre[j] <= w < pre[j+1] ----
+        for (uint32_t w0 = 0; w0 < T; w0 += 64) {
+            const uint32_t w = w0 + lane;
+            if (w < T) {
+                uint32_t lo = 0, hi = 64;  // largest j with s_pre[j] <= w (triangles with npx == 0 share a prefix and never win)
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s_pre[mid] <= w) lo = mid; else hi = mid;
+                }
+                const int4* tp = reinterpret_cast<const int4*>(&s_tri[lo]);
+                const int4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
+                const uint32_t flags = (uint32_t)q2.y, box = (uint32_t)q3.w;
+                const uint32_t k = w - s_pre[lo];
+                const uint32_t row = (k * (box >> 12)) >> 16, bw = ((box >> 8) & 15u) + 1u;
+                const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
+                bool inside;
+                float e1f, e2f;
+                if (!(flags & 1u)) {
+                    const int32_t eb0 = q0.z + __mul24(q0.x, lx) + __mul24(q0.y, ly);
+                    const int32_t eb1 = q1.y + __mul24(q0.w, lx) + __mul24(q1.x, ly);
+                    const int32_t eb2 = q2.x + __mul24(q1.z, lx) + __mul24(q1.w, ly);
+                    inside = (eb0 | eb1 | eb2) >= 0;
+                    e1f = (float)(eb1 + (int32_t)((flags >> 5) & 1u));
+                    e2f = (float)(eb2 + (int32_t)((flags >> 6) & 1u));
+                } else {
+                    const int4 ch = s_chi[lo];
+                    const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
+                    const long long c0 = ((long long)ch.x << 32) | (unsigned long long)(uint32_t)q0.z;
+                    const long long c1 = ((long long)ch.y << 32) | (unsigned long long)(uint32_t)q1.y;
+                    const long long c2 = ((long long)ch.z << 32) | (unsigned long long)(uint32_t)q2.x;
+                    const long long eb0 = c0 + (long long)q0.x * Xp + (long long)q0.y * Yp;
+                    const long long eb1 = c1 + (long long)q0.w * Xp + (long long)q1.x * Yp;
+                    const long long eb2 = c2 + (long long)q1.z * Xp + (long long)q1.w * Yp;
+                    inside = (eb0 | eb1 | eb2) >= 0;
+                    e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
+                    e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
+                }
+                const float rcpA = __int_as_float(q3.y);
+                const float b1 = e1f * rcpA, b2 = e2f * rcpA;
+                const float z = fmaf(b2, __int_as_float(q3.x), fmaf(b1, __int_as_float(q2.w), __int_as_float(q2.z)));
+                const bool pass = inside && z >= 0.0f && z <= 1.0f && z <= cd && lx < vw && ly < vh;
+                if (pass) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, (uint32_t)q3.z));
+            }
+        }
+        wave_lds_sync();  // the next pass overwrites s_tri / s_pre
+        a_cur = a_nxt;
+        ord_cur = ord_nxt;
+        ord_nxt = ord_nn;
+    }
+    wave_lds_sync();
+
+    // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame ----
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int32_t lx = (i & 1) * 8 + (int32_t)(lane & 7), ly = (i >> 1) * 8 + (int32_t)(lane >> 3);
+        if (lx >= vw || ly >= vh) continue;
+        const uint32_t x = (uint32_t)(binx0 + lx), y = (uint32_t)(biny0 + ly);
+        const unsigned long long key = s_key[ly * MTR_BIN + lx];
+        uint32_t col = P.clear_rgba8;
+        float dep = cd;
+        if (key != 0ull) {
+            dep = __uint_as_float(~(uint32_t)(key >> 32));
+            const uint32_t ord = (uint32_t)key - 1u;
+            const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
+            const RecA a = P.fb.rec_a[r];
+            const DMat mat = P.mats[a.mat];
+            if (TEX && mat.shader == MTR_SH_TEXTURED) {
+                const RecB b = P.fb.rec_b[r];
+                col = shade_textured(a, b, mat, (int32_t)x, (int32_t)y);
+            } else {
+                col = mat.rgba8;
+            }
+        }
+        const size_t pi = (size_t)y * P.fb.W + x;
+        reinterpret_cast<uint32_t*>(P.color)[pi] = col;
+        P.depth[pi] = dep;
+    }
+}
+
+}  // namespace mtr
+
+void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
+    const uint32_t nbins = p.fb.nbx * p.fb.nby;
+    const uint32_t world = p.fb.shard_world ? p.fb.shard_world : 1u;
+    uint32_t mine = (nbins + world - 1 - p.fb.shard_rank) / world;
+    if (mine == 0) return;
+    uint32_t grid = (mine + 7) / 8 * 8;
+    if (textured) hipLaunchKernelGGL(mtr::k_tile_vis<true>, dim3(grid), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(mtr::k_tile_vis<false>, dim3(grid), dim3(64), 0, s, p);
+}

@@ -30,6 +30,7 @@ struct mtr_device {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    int tile_mode = MTR_TILE_AUTO;
     std::string err;
     // grow-only intermediate buffers, shared by every frame of this device (frames execute in
     // stream order, so a later frame never overlaps an earlier one's use of them)
@@ -43,7 +44,7 @@ struct mtr_device {
     uint32_t* bin_start = nullptr;
     uint32_t* seg_start = nullptr;
     uint32_t bin_cap = 0;
-    uint32_t* entries = nullptr;
+    uint2* entries = nullptr;  // {record id, submission order}
     Seg* segs = nullptr;
     uint32_t entry_cap = 0, seg_cap = 0;
     DMat* mats = nullptr;
@@ -56,6 +57,7 @@ struct mtr_texture {
     mtr_device* dev;
     uint32_t w, h, fmt;
     uint8_t* d_rgba;
+    bool opaque;  // every decoded texel has alpha == 255: sampling it yields a == 1 exactly
 };
 
 struct mtr_model {
@@ -115,7 +117,7 @@ struct mtr_frame {
     uint32_t shard_rank = 0, shard_world = 1;
     std::vector<Draw> draws;
     std::vector<DMat> mats_host;  // kept alive until the async upload has certainly been consumed
-    bool submitted = false, waited = false;
+    bool submitted = false, waited = false, all_opaque = true;
     mtr_frame_stats stats{};
     hipEvent_t ev[MTR_STAGE_COUNT + 1] = {};
     bool have_events = false;
@@ -273,6 +275,14 @@ void mtr_device_destroy(mtr_device* d) {
     delete d;
 }
 
+int32_t mtr_device_set_tile_mode(mtr_device* d, int32_t mode) {
+    if (!d) return MTR_E_INVALID;
+    if (mode != MTR_TILE_AUTO && mode != MTR_TILE_ORDERED && mode != MTR_TILE_VISIBILITY)
+        return fail(d, MTR_E_INVALID, "unknown tile mode");
+    d->tile_mode = mode;
+    return MTR_OK;
+}
+
 int32_t mtr_device_set_profiling(mtr_device* d, int32_t enable) {
     if (!d) return MTR_E_INVALID;
     d->profiling = enable != 0;
@@ -311,6 +321,18 @@ int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, 
         HIPCHK(d, hipGetLastError());
         HIPCHK(d, hipStreamSynchronize(d->stream));
         (void)hipFree(d_blocks);
+    }
+    {
+        uint32_t* d_min = nullptr;
+        uint32_t h_min = 255;
+        if ((rc = dev_alloc(d, &d_min, 1))) return rc;
+        HIPCHK(d, hipMemcpyAsync(d_min, &h_min, 4, hipMemcpyHostToDevice, d->stream));
+        mtr_launch_alpha_min(t->d_rgba, (size_t)w * h, d_min, d->stream);
+        HIPCHK(d, hipGetLastError());
+        HIPCHK(d, hipMemcpyAsync(&h_min, d_min, 4, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        (void)hipFree(d_min);
+        t->opaque = h_min == 255;
     }
     *out = t.release();
     return MTR_OK;
@@ -709,6 +731,7 @@ static int32_t run_frame(mtr_frame* f) {
     // ---- material table ----
     std::vector<DMat>& mats = f->mats_host;
     mats.clear();
+    f->all_opaque = true;
     mats.reserve(nmats);
     std::vector<uint32_t> mat_base(f->draws.size()), mat_stride(f->draws.size());
     for (size_t di = 0; di < f->draws.size(); di++) {
@@ -727,6 +750,7 @@ static int32_t run_frame(mtr_frame* f) {
                     dm.shader = MTR_SH_CONST; dm.rgba8 = dr.const_rgba8;
                 } else if (tex >= 0 && m->prims[p].has_uv) {  // src/model.rs:212-216
                     dm.shader = MTR_SH_TEXTURED;
+                    if (!m->textures[(size_t)tex]->opaque) f->all_opaque = false;
                     dm.tex = m->textures[(size_t)tex]->d_rgba; dm.tw = m->textures[(size_t)tex]->w; dm.th = m->textures[(size_t)tex]->h;
                 } else {
                     dm.shader = MTR_SH_DEBUG; dm.rgba8 = m->debug_rgba8[p];
@@ -782,10 +806,19 @@ static int32_t run_frame(mtr_frame* f) {
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
     bool any_textured = false;
     for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
-    mtr_launch_tile(tp, any_textured, d->stream);
+    // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a
+    // per-pixel (min z, latest) reduction and the visibility-key kernel applies; otherwise blend order matters
+    const bool use_vis = f->all_opaque && d->tile_mode != MTR_TILE_ORDERED;
+    f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : MTR_TILE_ORDERED;
+    if (use_vis) mtr_launch_tile_vis(tp, any_textured, d->stream);
+    else mtr_launch_tile(tp, any_textured, d->stream);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], d->stream));
     HIPCHK(d, hipGetLastError());
-    f->stats = mtr_frame_stats{};
+    {
+        const uint32_t tk = f->stats.tile_kernel;
+        f->stats = mtr_frame_stats{};
+        f->stats.tile_kernel = tk;
+    }
     f->stats.tris_in = tris_in;
     f->stats.width = f->w; f->stats.height = f->h; f->stats.nbins = nbins; f->stats.ndraws = (uint32_t)f->draws.size();
     return MTR_OK;
@@ -913,6 +946,20 @@ int32_t mtr_frame_get_timings(mtr_frame* f, float ms[MTR_STAGE_COUNT]) {
 // ---------------------------------------------------------------------------------------------
 // unit-test hooks
 // ---------------------------------------------------------------------------------------------
+int32_t mtr_frame_read_bin_counts(mtr_frame* f, uint32_t* entries, uint32_t* segments, size_t nbins) {
+    if (!f || !entries || !segments) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    if (nbins != f->stats.nbins) return fail(d, MTR_E_INVALID, "nbins mismatch");
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    std::vector<uint32_t> bs(nbins + 1), ss(nbins + 1);
+    HIPCHK(d, hipMemcpyAsync(bs.data(), d->bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipMemcpyAsync(ss.data(), d->seg_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    for (size_t b = 0; b < nbins; b++) { entries[b] = bs[b + 1] - bs[b]; segments[b] = ss[b + 1] - ss[b]; }
+    return MTR_OK;
+}
+
 int32_t mtr_model_vertex_stage(mtr_model* m, size_t prim, const float M[16], float* out_clip, float* out_uv) {
     if (!m || !M || !out_clip || !out_uv) return MTR_E_INVALID;
     mtr_device* d = m->dev;

@@ -88,7 +88,7 @@ struct FrameBuffers {
     unsigned long long* bin_fill;
     uint32_t* bin_start;            // nbins + 1
     uint32_t* seg_start;            // nbins + 1
-    uint32_t* entries;
+    uint2* entries;                 // x = record id, y = submission order (chunk*128 + round*64 + rank)
     Seg* segs;
     uint32_t* counters;             // CTR_*
     uint32_t rec_cap, entry_cap, seg_cap;
@@ -126,6 +126,8 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s);
 void mtr_launch_scan(const FrameBuffers& fb, hipStream_t s);
 void mtr_launch_fill(const FrameBuffers& fb, uint32_t total_chunks, hipStream_t s);
 void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s);
+void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s);
+void mtr_launch_alpha_min(const uint8_t* rgba, size_t npixels, uint32_t* out_min, hipStream_t s);
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s);
 void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
 void mtr_launch_bc7_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);

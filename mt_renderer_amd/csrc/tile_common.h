@@ -1,0 +1,93 @@
+// tile_common.h -- fragment-stage helpers shared by the ordered (k_tile.hip) and visibility
+// (k_tile_vis.hip) tile kernels.  Every formula is SPEC.md section 7, bit for bit.
+#pragma once
+#include "mtr_internal.h"
+
+namespace mtr {
+
+__device__ __forceinline__ float unorm8f(uint32_t v) { return (float)(v & 0xffu) / 255.0f; }
+__device__ __forceinline__ uint32_t quant8(float x) {
+    if (!(x > 0.0f)) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    return (uint32_t)rintf(x * 255.0f);
+}
+__device__ __forceinline__ int32_t clamp_texel(float f, uint32_t n) {
+    if (!(f >= 0.0f)) f = 0.0f;
+    if (f > (float)(n - 1)) f = (float)(n - 1);
+    return (int32_t)f;
+}
+struct TexRef {
+    const uint8_t* tex;
+    uint32_t tw, th;
+};
+__device__ __forceinline__ void texel_f(const TexRef& m, int32_t x, int32_t y, float (&o)[4]) {
+    uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[(size_t)y * m.tw + (size_t)x];
+    o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
+}
+
+// textureSample: clamp-to-edge, mag linear / min nearest, one level (src/texture.rs:21,33-42).
+__device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v, bool linear, float (&o)[4]) {
+    const float fw = (float)m.tw, fh = (float)m.th;
+    if (!linear) {
+        texel_f(m, clamp_texel(floorf(u * fw), m.tw), clamp_texel(floorf(v * fh), m.th), o);
+        return;
+    }
+    float x = u * fw - 0.5f, y = v * fh - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int32_t ix0 = clamp_texel(x0, m.tw), ix1 = clamp_texel(x0 + 1.0f, m.tw);
+    int32_t iy0 = clamp_texel(y0, m.th), iy1 = clamp_texel(y0 + 1.0f, m.th);
+    float c00[4], c10[4], c01[4], c11[4];
+    texel_f(m, ix0, iy0, c00); texel_f(m, ix1, iy0, c10); texel_f(m, ix0, iy1, c01); texel_f(m, ix1, iy1, c11);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float top = fmaf(fx, c10[c] - c00[c], c00[c]);
+        float bot = fmaf(fx, c11[c] - c01[c], c01[c]);
+        o[c] = fmaf(fy, bot - top, top);
+    }
+}
+
+__device__ __forceinline__ bool filter_is_linear(float dudx, float dvdx, float dudy, float dvdy, uint32_t tw, uint32_t th) {
+    const float fw = (float)tw, fh = (float)th;
+    return (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) && (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
+}
+
+// SrcAlpha / OneMinusSrcAlpha colour, One / Zero alpha (src/model.rs:243-246), UNORM8 store
+__device__ __forceinline__ uint32_t blend_store(uint32_t dst, const float (&src)[4], bool blend) {
+    uint32_t out = 0;
+    if (blend) {
+        const float a = src[3], ia = 1.0f - a;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float d = unorm8f(dst >> (8 * c));
+            float t = d * ia;
+            out |= quant8(fmaf(src[c], a, t)) << (8 * c);
+        }
+        out |= quant8(src[3]) << 24;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; c++) out |= quant8(src[c]) << (8 * c);
+    }
+    return out;
+}
+
+// LDS traffic between lanes of ONE wave: ds operations of a wave complete in order; this only stops
+// the compiler from moving accesses across the hand-off point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous bin range.
+// Returns false when this block has no bin.
+__device__ __forceinline__ bool block_to_bin(const FrameBuffers& fb, uint32_t& bin) {
+    const uint32_t nbins = fb.nbx * fb.nby;
+    const uint32_t world = fb.shard_world ? fb.shard_world : 1u;
+    const uint32_t per = (gridDim.x + 7) / 8;
+    const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    bin = slot * world + fb.shard_rank;
+    return slot < (nbins + world - 1 - fb.shard_rank) / world && bin < nbins;
+}
+
+}  // namespace mtr

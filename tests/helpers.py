@@ -26,8 +26,17 @@ def render_oracle(w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, nthr
     return out
 
 
-def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, shard=None):
+def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, shard=None, tile_mode=None):
+    """tile_mode None: render the scene with BOTH tile kernels (ordered, then auto = visibility-key when every
+    material is opaque), require identical pixels, return the auto result."""
     from mt_renderer_amd import api
+    if tile_mode is None:
+        a = render_gpu(dev, w, h, draws, clear, clear_depth, shard, api.TILE_ORDERED)
+        b = render_gpu(dev, w, h, draws, clear, clear_depth, shard, api.TILE_AUTO)
+        assert a[2]["tile_kernel"] == api.TILE_ORDERED
+        assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all(), "tile kernels disagree"
+        return b
+    dev.set_tile_mode(tile_mode)
     fr = api.Frame(dev, w, h, clear, clear_depth)
     if shard:
         fr.set_shard(*shard)
@@ -51,6 +60,7 @@ def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, sh
         fr.end()
         return fr.color(), fr.depth(), fr.stats()
     finally:
+        dev.set_tile_mode(api.TILE_AUTO)
         fr.close()
         for b in batches:
             b.close()

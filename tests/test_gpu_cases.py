@@ -340,3 +340,45 @@ def test_random_clip_space_soup(gpu_device, seed):
     M = rng.normal(0, 1, size=(4, 4))
     M[3] = (0.1 * rng.normal(), 0.1 * rng.normal(), -1.0, 0.8)  # w depends on z: some vertices behind the eye
     _both(gpu_device, 200, 120, [dict(md=md, M=scene.to_f32_colmajor(M))])
+
+
+def test_tile_kernel_selection(gpu_device):
+    """AUTO picks the visibility-key kernel exactly when every material is opaque."""
+    from mt_renderer_amd import api
+    w, h = 96, 64
+    opaque = scene.random_bc7_texture(32, 32, 5, opaque_modes_only=True)
+    translucent = scene.checker_rgba8_texture(8, 8, 1, alpha=(255, 254))
+    q = [_quad(4, 4, 60, 60, .5, tex=0)]
+    for texs, want in (([opaque], api.TILE_VISIBILITY), ([translucent], api.TILE_ORDERED)):
+        md = pixel_model(q, texs)
+        g = render_gpu(gpu_device, w, h, [dict(md=md, M=pixel_to_ndc_matrix(w, h))], tile_mode=api.TILE_AUTO)
+        assert g[2]["tile_kernel"] == want
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=8, cols=10)
+    g = render_gpu(gpu_device, w, h, [dict(md=md, M=scene.to_f32_colmajor(scene.headline_transform(w, h)))], tile_mode=api.TILE_AUTO)
+    assert g[2]["tile_kernel"] == api.TILE_VISIBILITY
+    # forcing VISIBILITY on an ineligible frame falls back to the ordered kernel
+    md = pixel_model(q, [translucent])
+    g = render_gpu(gpu_device, w, h, [dict(md=md, M=pixel_to_ndc_matrix(w, h))], tile_mode=api.TILE_VISIBILITY)
+    assert g[2]["tile_kernel"] == api.TILE_ORDERED
+
+
+def test_opaque_textures_deferred_shading(gpu_device):
+    """Opaque textures go through the visibility kernel's deferred shading: magnified, minified, the rho = 1
+    switch, perspective, near clip, equal-depth ties and many layers -- identical to the ordered kernel and the oracle."""
+    texs = [scene.random_bc7_texture(64, 64, 31, opaque_modes_only=True), scene.checker_rgba8_texture(4, 4, 1),
+            scene.checker_rgba8_texture(32, 32, 1)]
+    prims = [_quad(0, 0, 8, 8, .5, tex=0), _quad(10, 0, 74, 64, .5, tex=1), _quad(0, 10, 40, 50, .6, tex=0),
+             _quad(20, 30, 60, 60, .6, tex=2), _quad(20, 30, 60, 60, .6, tex=1),      # same depth: the later one wins
+             _quad(30, 5, 62, 37, .45, tex=0, u0=-0.5, v0=-0.25, u1=1.5, v1=1.25), _quad(5, 40, 30, 63, .3, tex=-1, did=9)]
+    g = _px(gpu_device, prims, w=80, h=64, textures=texs)
+    assert g[2]["tile_kernel"] == 2
+    for scale in (1.0, 1.0000001, 0.9999999):
+        _px(gpu_device, [_quad(0, 0, 32, 32, .5, u1=scale, v1=scale, tex=2)], w=32, h=32, textures=texs)
+    w, h = 640, 360
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=30, cols=48, textured=True, textures=[texs[0]])
+    M = scene.to_f32_colmajor(scene.headline_transform(w, h))
+    g = _both(gpu_device, w, h, [dict(md=md, M=M, palette=scene.bone_palette())])
+    assert g[2]["tile_kernel"] == 2
+    vp = scene.reference_view_proj(w, h)
+    M2 = scene.to_f32_colmajor(vp @ scene.mat_translate(-5.0, 0.0, 1.0 - 0.3) @ scene.mat_rot_x(0.5))
+    _both(gpu_device, w, h, [dict(md=md, M=M2, palette=scene.bone_palette())])
