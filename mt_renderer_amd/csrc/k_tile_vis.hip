@@ -132,39 +132,49 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
     return blend_store(0u, src, false);  // opaque texture: a == 1 exactly, so the blend is a replace
 }
 
-template <bool TEX>
-__global__ __launch_bounds__(64) void k_tile_vis(TileParams P) {
-    __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
-    __shared__ __align__(16) VisTri s_tri[64];
-    __shared__ __align__(16) int4 s_chi[64];
-    __shared__ uint32_t s_pre[65];
+// waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
+// the keys are order-independent, so the waves only meet at the two barriers around the raster loop.  This
+// cuts the serial chain of the heaviest bins (the long pole of the kernel) by VIS_WAVES.
+#define VIS_WAVES 4
 
-    const uint32_t lane = threadIdx.x;
+template <bool TEX>
+__global__ __launch_bounds__(64 * VIS_WAVES) void k_tile_vis(TileParams P) {
+    __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
+    __shared__ __align__(16) VisTri s_tri_all[VIS_WAVES][64];
+    __shared__ __align__(16) int4 s_chi_all[VIS_WAVES][64];
+    __shared__ uint32_t s_pre_all[VIS_WAVES][65];
+
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    VisTri* s_tri = s_tri_all[wv];
+    int4* s_chi = s_chi_all[wv];
+    uint32_t* s_pre = s_pre_all[wv];
     uint32_t bin;
-    if (!block_to_bin(P.fb, bin)) return;
+    if (!block_to_bin(P.fb, bin)) return;  // uniform over the workgroup, before any barrier
     const uint32_t nbx = P.fb.nbx;
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
     const float cd = P.clear_depth;
     const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
-#pragma unroll
-    for (int i = 0; i < 4; i++) s_key[lane + 64 * i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
+    __syncthreads();
 
     const uint32_t ent_lo = P.fb.bin_start[bin], N = P.fb.bin_start[bin + 1] - ent_lo;
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
-    // record loads of pass k+1 and the entry loads of pass k+2 are in flight.  The record of an entry is
-    // addressable from its submission order: chunk run base = chunk * MTR_CHUNK_SLOTS.
+    // record loads of this wave's next pass and the entry loads of the one after are in flight.  The record of an
+    // entry is addressable from its submission order: chunk run base = chunk * MTR_CHUNK_SLOTS.
+    const uint32_t stride = 64 * VIS_WAVES, first = wv * 64;
     uint32_t ord_cur = 0, ord_nxt = 0;
-    if (lane < N) ord_cur = P.fb.entries[ent_lo + lane].y;
-    if (64 + lane < N) ord_nxt = P.fb.entries[ent_lo + 64 + lane].y;
+    if (first + lane < N) ord_cur = P.fb.entries[ent_lo + first + lane].y;
+    if (first + stride + lane < N) ord_nxt = P.fb.entries[ent_lo + first + stride + lane].y;
     RecA a_cur = zero_rec;
-    if (lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
-    for (uint32_t e0 = 0; e0 < N; e0 += 64) {
+    if (first + lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
+    for (uint32_t e0 = first; e0 < N; e0 += stride) {
         const bool valid = e0 + lane < N;
         RecA a_nxt = zero_rec;
-        if (e0 + 64 + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
+        if (e0 + stride + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
         uint32_t ord_nn = 0;
-        if (e0 + 128 + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 128 + lane].y;
+        if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane].y;
 
         Setup s;
         s.npx = 0;
@@ -235,12 +245,12 @@ __global__ __launch_bounds__(64) void k_tile_vis(TileParams P) {
         ord_cur = ord_nxt;
         ord_nxt = ord_nn;
     }
-    wave_lds_sync();
+    __syncthreads();
 
-    // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame ----
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int32_t lx = (i & 1) * 8 + (int32_t)(lane & 7), ly = (i >> 1) * 8 + (int32_t)(lane >> 3);
+    // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame;
+    //      one pixel per thread, rows of 16 pixels = 64 contiguous bytes ----
+    for (uint32_t pidx = threadIdx.x; pidx < MTR_BIN * MTR_BIN; pidx += 64 * VIS_WAVES) {
+        const int32_t lx = (int32_t)(pidx & (MTR_BIN - 1)), ly = (int32_t)(pidx >> MTR_BIN_SHIFT);
         if (lx >= vw || ly >= vh) continue;
         const uint32_t x = (uint32_t)(binx0 + lx), y = (uint32_t)(biny0 + ly);
         const unsigned long long key = s_key[ly * MTR_BIN + lx];
@@ -273,6 +283,6 @@ void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
     uint32_t mine = (nbins + world - 1 - p.fb.shard_rank) / world;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
-    if (textured) hipLaunchKernelGGL(mtr::k_tile_vis<true>, dim3(grid), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(mtr::k_tile_vis<false>, dim3(grid), dim3(64), 0, s, p);
+    if (textured) hipLaunchKernelGGL(mtr::k_tile_vis<true>, dim3(grid), dim3(64 * VIS_WAVES), 0, s, p);
+    else hipLaunchKernelGGL(mtr::k_tile_vis<false>, dim3(grid), dim3(64 * VIS_WAVES), 0, s, p);
 }
