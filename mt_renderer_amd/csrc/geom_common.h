@@ -110,6 +110,81 @@ __device__ __forceinline__ VOut shade_vertex(const uint8_t* vbuf, const DPrim& p
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same vertex shader on the matrix cores: v_mfma_f32_4x4x1_16b_f32 = 16 independent
+// (4x1)*(1x4) outer products per wave; block = 4 consecutive lanes, D[lane][v] = A[block*4+v] * B[lane]
+// + C, and a k-step chain is bitwise an fmaf chain (tools/mfma_probe.hip, run on gfx950).  One lane =
+// one vertex supplies B (its own w_k*p_c, or q_c) and row (lane & 3) of the 4x4 matrix as A:
+//   * clip = M * (q,1): A is the wave-uniform M -> 4 MFMAs for 64 vertices;
+//   * skinning: A is the bone matrix P[j_k], so a block must share its four joint indices (rows of a
+//     skinned mesh do) -> 16 MFMAs; blocks that do not are redone by their lanes with the VALU chain,
+//     which is the identical arithmetic.
+// Must be called by all 64 lanes of the wave (the MFMA is wave-wide); `active` masks the loads.
+// ---------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ VOut shade_vertex_mfma(const uint8_t* vbuf, const DPrim& pr, uint32_t vid, bool active,
+                                                  const float (&M)[16], const float* s_pal, uint32_t npal, bool skinned) {
+    const uint32_t lane = threadIdx.x & 63, row = lane & 3;
+    const bool al4 = pr.aligned4 != 0;
+    float px = 0.0f, py = 0.0f, pz = 0.0f, tu = 0.0f, tv = 0.0f, tz;
+    uint32_t jw = 0, ww = 0;
+    if (active) {
+        const uint8_t* vp = vbuf + pr.vertex_base + (size_t)vid * pr.stride;
+        decode_elem(pr.pos_fmt, pr.pos_cnt, vp + pr.pos_off, al4, px, py, pz);
+        if (pr.has_uv) decode_elem(pr.uv_fmt, pr.uv_cnt, vp + pr.uv_off, al4, tu, tv, tz);
+        if (skinned) { jw = ld32(vp + pr.joint_off, al4); ww = ld32(vp + pr.weight_off, al4); }
+    }
+    float q0 = px, q1 = py, q2 = pz;
+    if (skinned) {  // wave-uniform
+        const float pin[4] = {px, py, pz, 1.0f};
+        const uint32_t jw0 = (uint32_t)__shfl((int)jw, (int)(lane & ~3u));
+        const uint64_t okm = __ballot(active && jw == jw0);
+        const bool coherent = ((okm >> (lane & ~3u)) & 0xFull) == 0xFull;
+        v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t j = (jw0 >> (8 * k)) & 0xff;
+            if (j >= npal) j = npal - 1;
+            const float wk = unorm8f(ww >> (8 * k));
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(s_pal[j * 16 + c * 4 + row], wk * pin[c], acc, 0, 0, 0);
+        }
+        q0 = acc[0]; q1 = acc[1]; q2 = acc[2];
+        if (__ballot(active && !coherent)) {
+            if (active && !coherent) {
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t j = (jw >> (8 * k)) & 0xff;
+                    if (j >= npal) j = npal - 1;
+                    const float4* P = reinterpret_cast<const float4*>(s_pal + j * 16);
+                    const float wk = unorm8f(ww >> (8 * k));
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float4 col = P[c];
+                        const float s = wk * pin[c];
+                        a0 = fmaf(col.x, s, a0);
+                        a1 = fmaf(col.y, s, a1);
+                        a2 = fmaf(col.z, s, a2);
+                    }
+                }
+                q0 = a0; q1 = a1; q2 = a2;
+            }
+        }
+    }
+    const float q[4] = {q0, q1, q2, 1.0f};
+    v4f cl = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float a = row == 0 ? M[c * 4 + 0] : row == 1 ? M[c * 4 + 1] : row == 2 ? M[c * 4 + 2] : M[c * 4 + 3];
+        cl = __builtin_amdgcn_mfma_f32_4x4x1f32(a, q[c], cl, 0, 0, 0);
+    }
+    VOut r = {cl[0], cl[1], cl[2], cl[3], tu, tv};
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 // bin iteration shared by k_geom (count) and k_fill (fill): one round = up to 64 records, one per
 // lane, in record order.  Lanes whose current bin equals the wave-minimum current bin form a group;
 // f(bin, group_mask, is_member) runs once per group, groups in increasing bin order, so both

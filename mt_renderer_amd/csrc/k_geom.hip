@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     // ---- vertex stage ----
     PV me;
     me.X = 0; me.Y = 0; me.z = 0.0f; me.iw = 0.0f; me.up = 0.0f; me.vp = 0.0f; me.flags = 0;
+    // skinning + MVP on the matrix cores, wave-wide (all 64 lanes issue the MFMAs; invalid lanes carry zeros)
+    const VOut v = shade_vertex_mfma(P.vbuf, pr, vid, vvalid, M, s_pal, P.npal, skinned);
     if (vvalid) {
-        VOut v = shade_vertex(P.vbuf, pr, vid, M, s_pal, P.npal, skinned);
         me = project(v, W, H);
         me.flags |= 1u | (outcode(v) << 2);
     }
@@ -244,16 +245,18 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     }
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
+    // texcoord planes are only read by textured materials: do not spend 48 B/triangle of HBM writes otherwise
+    const bool want_b = pr.has_uv && P.mats[mat].shader == MTR_SH_TEXTURED;
     if (n_out >= 1) {
         P.fb.rec_a[base + rank] = r0.a;
         P.fb.rec_hdr[base + rank] = r0.h;
-        if (pr.has_uv) P.fb.rec_b[base + rank] = r0.b;
+        if (want_b) P.fb.rec_b[base + rank] = r0.b;
         s_hdr[wave][rank] = r0.h;
     }
     if (n_out == 2) {
         P.fb.rec_a[base + rank + 1] = r1.a;
         P.fb.rec_hdr[base + rank + 1] = r1.h;
-        if (pr.has_uv) P.fb.rec_b[base + rank + 1] = r1.b;
+        if (want_b) P.fb.rec_b[base + rank + 1] = r1.b;
         s_hdr[wave][rank + 1] = r1.h;
     }
     // s_hdr[wave] is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
@@ -283,9 +286,11 @@ __global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t pri
     compose_matrix(P, 0, M);
     const DPrim pr = P.prims[prim];
     const bool skinned = pr.skinnable && P.palettes && P.npal;
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    // whole waves call the MFMA path; the tail of the last wave is masked
+    if ((v & ~63u) >= pr.vertex_num) return;
+    const VOut o = shade_vertex_mfma(P.vbuf, pr, v, v < pr.vertex_num, M, s_pal, P.npal, skinned);
     if (v >= pr.vertex_num) return;
-    VOut o = shade_vertex(P.vbuf, pr, v, M, s_pal, P.npal, skinned);
     out_clip[4 * v + 0] = o.x; out_clip[4 * v + 1] = o.y; out_clip[4 * v + 2] = o.z; out_clip[4 * v + 3] = o.w;
     out_uv[2 * v + 0] = o.u; out_uv[2 * v + 1] = o.v;
 }

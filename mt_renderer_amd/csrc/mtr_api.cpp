@@ -793,6 +793,7 @@ static int32_t run_frame(mtr_frame* f) {
         memcpy(gp.vp, dr.vp, sizeof gp.vp);
         gp.chunk_base = chunk_base; gp.mat_base = mat_base[di]; gp.mat_inst_stride = mat_stride[di];
         gp.fb = fb;
+        gp.mats = d->mats;
         mtr_launch_geom(gp, d->stream);
         chunk_base += gp.nchunks * dr.ninst;
     }

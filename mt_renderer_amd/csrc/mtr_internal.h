@@ -109,6 +109,7 @@ struct GeomParams {
     float vp[16];
     uint32_t chunk_base;      // global chunk id of (instance 0, chunk 0)
     uint32_t mat_base, mat_inst_stride;
+    const DMat* mats;         // frame material table (read: is this primitive textured?)
     FrameBuffers fb;
 };
 
