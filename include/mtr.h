@@ -82,7 +82,7 @@ typedef struct mtr_frame_stats {
     uint64_t segments;    /* per-bin ordered runs */
     uint32_t width, height, nbins, ndraws;
     uint32_t tile_kernel; /* MTR_TILE_ORDERED or MTR_TILE_VISIBILITY: which tile kernel rendered the frame */
-    uint32_t pad;
+    uint32_t binning;     /* 1 = single-pass bounded queues, 2 = exact two-pass (count, scan, fill) queues */
 } mtr_frame_stats;
 
 /* stage timings of the last submitted frame, milliseconds, from hipEvents recorded on the
@@ -101,6 +101,10 @@ int32_t mtr_device_set_profiling(mtr_device *dev, int32_t enable);
  * kernel.  ORDERED forces the ordered kernel (tests compare both); VISIBILITY is honoured only when eligible. */
 enum { MTR_TILE_AUTO = 0, MTR_TILE_ORDERED = 1, MTR_TILE_VISIBILITY = 2 };
 int32_t mtr_device_set_tile_mode(mtr_device *dev, int32_t mode);
+/* triangle -> bin queues.  single_pass != 0 (default): k_geom writes straight into bounded per-bin queues of
+ * queue_capacity entries (0 keeps the current bound); a frame that overflows a queue is transparently re-run with the
+ * exact two-pass queues (count, scan, fill) and the bound doubles for later frames.  single_pass == 0: always two-pass. */
+int32_t mtr_device_set_binning(mtr_device *dev, int32_t single_pass, uint32_t queue_capacity);
 int32_t mtr_abi_version(void);
 
 /* ---- Texture::new (src/texture.rs:11-30): level 0 only, 2-D, decoded on upload ---- */

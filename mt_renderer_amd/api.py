@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "mtr_frame_wait", "mtr_frame_end", "mtr_frame_read_color", "mtr_frame_read_depth", "mtr_frame_color_devptr",
     "mtr_frame_depth_devptr", "mtr_frame_get_stats", "mtr_frame_get_timings", "mtr_frame_destroy",
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
-    "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode",
+    "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
 ]
 
 
@@ -59,7 +59,7 @@ class _Layout(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
                 ("segments", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("nbins", C.c_uint32),
-                ("ndraws", C.c_uint32), ("tile_kernel", C.c_uint32), ("pad", C.c_uint32)]
+                ("ndraws", C.c_uint32), ("tile_kernel", C.c_uint32), ("binning", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -110,6 +110,7 @@ def _load() -> C.CDLL:
         "mtr_device_unpack_color_shards": (i32, [vp, vp, u32, u32, u32, vp]),
         "mtr_frame_read_bin_counts": (i32, [vp, vp, vp, sz]),
         "mtr_device_set_tile_mode": (i32, [vp, i32]),
+        "mtr_device_set_binning": (i32, [vp, i32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -157,6 +158,10 @@ class Device:
     def set_tile_mode(self, mode: int):
         """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""
         self.check(lib.mtr_device_set_tile_mode(self._h, mode))
+
+    def set_binning(self, single_pass: bool, queue_capacity: int = 0):
+        """single-pass bounded bin queues (default) or the exact two-pass queues; see include/mtr.h."""
+        self.check(lib.mtr_device_set_binning(self._h, 1 if single_pass else 0, queue_capacity))
 
     def set_profiling(self, on: bool):
         self.check(lib.mtr_device_set_profiling(self._h, 1 if on else 0))

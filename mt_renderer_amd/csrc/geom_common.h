@@ -223,4 +223,57 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hands one round of records (lane = record `round*64 + lane` of chunk `gid`'s run) to the bin queues.
+// The (bin, lanes) groups are enumerated first; queue space for up to 64 groups is then reserved by ONE
+// wave-wide returning atomic (lane g reserves for group g), so the atomic round trip is paid once per
+// round instead of once per group; finally every member lane writes its entry and every group leader its
+// segment descriptor.  DIRECT: bounded per-bin queues (single-pass binning, k_geom); otherwise the exact
+// two-pass layout positioned by k_scan (k_fill).
+// ---------------------------------------------------------------------------------------------
+template <bool DIRECT>
+__device__ __forceinline__ void emit_bins(const FrameBuffers& fb, RecHdr h, bool act, uint32_t gid, uint32_t round, uint32_t lane) {
+    uint32_t gbin = 0, ng = 0;
+    uint64_t gmask = 0;
+    auto flush = [&]() {
+        if (ng == 0) return;
+        unsigned long long t = 0;
+        uint32_t qbase = 0, sbase = 0;
+        if (lane < ng) {
+            t = atomicAdd(&fb.bin_fill[gbin], (unsigned long long)__popcll(gmask) | (1ull << 32));
+            if (DIRECT) { qbase = gbin * fb.qcap; sbase = gbin * fb.scap; }
+            else { qbase = fb.bin_start[gbin]; sbase = fb.seg_start[gbin]; }
+        }
+        for (uint32_t gi = 0; gi < ng; gi++) {
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gmask >> 32), gi) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gmask, gi);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, gi);
+            const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), gi);
+            const uint32_t qb = (uint32_t)__builtin_amdgcn_readlane((int)qbase, gi);
+            const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)sbase, gi);
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            const bool fits = !DIRECT || (off + cnt <= fb.qcap && si < fb.scap);
+            if ((m >> lane) & 1ull) {
+                const bool leader = lane == (uint32_t)__ffsll((long long)m) - 1;
+                if (fits) {
+                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    fb.entries[qb + off + rank] = gid * 128u + round * 64u + lane;
+                    if (leader) {
+                        Seg sg = {gid * 2u + round, off, cnt, 0u};
+                        fb.segs[sb + si] = sg;
+                    }
+                } else if (leader) {
+                    atomicOr(&fb.counters[CTR_OVERFLOW], 4u);
+                }
+            }
+        }
+        ng = 0;
+    };
+    for_each_bin_group(h, act, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool) {
+        if (lane == ng) { gbin = bin; gmask = m; }
+        if (++ng == 64) flush();
+    });
+    flush();
+}
+
 }  // namespace mtr

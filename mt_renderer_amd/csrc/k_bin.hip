@@ -60,22 +60,7 @@ __global__ __launch_bounds__(256) void k_fill(FrameBuffers fb, uint32_t total_ch
         const bool act = j < ci.n;
         RecHdr h = {0, 0, 0, 0};
         if (act) h = fb.rec_hdr[ci.base + j];
-        for_each_bin_group(h, act, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool hit) {
-            const uint32_t leader = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)m) - 1);
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            unsigned long long t = 0;
-            if (hit && lane == leader) t = atomicAdd(&fb.bin_fill[bin], (unsigned long long)cnt | (1ull << 32));
-            const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)t, leader);
-            const uint32_t thi = __builtin_amdgcn_readlane((uint32_t)(t >> 32), leader);
-            if (hit) {
-                const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                fb.entries[fb.bin_start[bin] + tlo + rank] = make_uint2(ci.base + j, gid * 128u + j);
-                if (lane == leader) {
-                    Seg sg = {gid * 2u + round, tlo, cnt, 0u};
-                    fb.segs[fb.seg_start[bin] + thi] = sg;
-                }
-            }
-        });
+        emit_bins<false>(fb, h, act, gid, round, lane);
     }
 }
 

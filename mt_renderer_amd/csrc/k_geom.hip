@@ -122,6 +122,7 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
     __syncthreads();
 }
 
+template <bool DIRECT>
 __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
@@ -264,17 +265,22 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- triangle -> bin counting: one atomic per (wave, bin) group ----
+    // ---- triangle -> bin: DIRECT = single-pass binning straight into the bounded per-bin queues;
+    //      otherwise count only (one non-returning atomic per (wave, bin) group), k_scan + k_fill follow ----
     for (uint32_t round = 0; round * 64 < total; ++round) {
         const uint32_t j = round * 64 + lane;
         const bool act = j < total;
         RecHdr h = {0, 0, 0, 0};
         if (act) h = s_hdr[wave][j];
-        for_each_bin_group(h, act, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world,
-                           [&](uint32_t bin, uint64_t m, bool hit) {
-                               if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
-                                   atomicAdd(&P.fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
-                           });
+        if (DIRECT) {
+            emit_bins<true>(P.fb, h, act, gid, round, lane);
+        } else {
+            for_each_bin_group(h, act, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world,
+                               [&](uint32_t bin, uint64_t m, bool hit) {
+                                   if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
+                                       atomicAdd(&P.fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
+                               });
+        }
     }
 }
 
@@ -303,7 +309,8 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
     dim3 grid(nblk, p.ninst);
     size_t lds = (size_t)p.npal * 64;
-    hipLaunchKernelGGL(mtr::k_geom, grid, dim3(256), lds, s, p);
+    if (p.fb.direct) hipLaunchKernelGGL(mtr::k_geom<true>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(mtr::k_geom<false>, grid, dim3(256), lds, s, p);
 }
 
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s) {

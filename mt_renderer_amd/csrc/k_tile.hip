@@ -127,8 +127,12 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
 #pragma unroll
     for (int i = 0; i < 4; i++) { dep[i] = P.clear_depth; col[i] = P.clear_rgba8; }
 
-    const uint32_t seg_lo = P.fb.seg_start[bin], S = P.fb.seg_start[bin + 1] - seg_lo;
-    const uint32_t ent_lo = P.fb.bin_start[bin];
+    uint32_t seg_lo, S, ent_lo, n_ent;
+    bin_queue(P.fb, bin, ent_lo, n_ent, seg_lo, S);
+    if (P.fb.direct && lane == 0 && n_ent) {  // queue statistics (direct mode has no scan to count them)
+        atomicAdd(&P.fb.counters[CTR_ENT_SHARDS + (bin & (CTR_NSHARDS - 1))], n_ent);
+        atomicAdd(&P.fb.counters[CTR_SEG_SHARDS + (bin & (CTR_NSHARDS - 1))], S);
+    }
     const Seg* segs = P.fb.segs + seg_lo;
 
     // ---- key ranges [lo, hi): one pass when the bin holds <= 64 segments ----
@@ -212,7 +216,8 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                         const uint32_t mid = (a + b) >> 1;
                         if (s_pre[mid] <= e) a = mid; else b = mid;
                     }
-                    const uint32_t r = P.fb.entries[ent_lo + s_off[a] + (e - s_pre[a])].x;
+                    const uint32_t ord = P.fb.entries[ent_lo + s_off[a] + (e - s_pre[a])];
+                    const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
                     setup_entry<TEX>(P, r, binx0, biny0, s_tc[lane], TEX ? &s_tx[lane] : nullptr, s_chi[lane], s_mask[lane]);
                 }
                 wave_lds_sync();

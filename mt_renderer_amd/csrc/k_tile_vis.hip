@@ -16,7 +16,8 @@
 //     defines them -- per pixel, then the only framebuffer write of the frame.
 // Same arithmetic per fragment as k_tile.hip, bit for bit; the host picks this kernel only when the
 // frame is eligible (mtr_api.cpp); tests run both kernels on the same scenes.
-// One wave per 16x16 bin, no workgroup barriers, no segment sort (order rides in the entry).
+// VIS_WAVES waves per 16x16 bin (passes dealt round-robin, two workgroup barriers in total), no segment
+// sort (the submission order rides in the entry).
 #include "tile_common.h"
 
 namespace mtr {
@@ -135,7 +136,9 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
 // waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
 // the keys are order-independent, so the waves only meet at the two barriers around the raster loop.  This
 // cuts the serial chain of the heaviest bins (the long pole of the kernel) by VIS_WAVES.
-#define VIS_WAVES 4
+#ifndef VIS_WAVES
+#define VIS_WAVES 2  // measured on the headline scene (tools/sweep_vis_waves.sh): 1: 104 us, 2: 73 us, 4: 83 us, 8: 129 us
+#endif
 
 template <bool TEX>
 __global__ __launch_bounds__(64 * VIS_WAVES) void k_tile_vis(TileParams P) {
@@ -158,15 +161,20 @@ __global__ __launch_bounds__(64 * VIS_WAVES) void k_tile_vis(TileParams P) {
     for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
     __syncthreads();
 
-    const uint32_t ent_lo = P.fb.bin_start[bin], N = P.fb.bin_start[bin + 1] - ent_lo;
+    uint32_t ent_lo, N, seg_lo_unused, n_seg;
+    bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
+    if (P.fb.direct && threadIdx.x == 0 && N) {  // queue statistics (direct mode has no scan to count them)
+        atomicAdd(&P.fb.counters[CTR_ENT_SHARDS + (bin & (CTR_NSHARDS - 1))], N);
+        atomicAdd(&P.fb.counters[CTR_SEG_SHARDS + (bin & (CTR_NSHARDS - 1))], n_seg);
+    }
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
     // record loads of this wave's next pass and the entry loads of the one after are in flight.  The record of an
     // entry is addressable from its submission order: chunk run base = chunk * MTR_CHUNK_SLOTS.
     const uint32_t stride = 64 * VIS_WAVES, first = wv * 64;
     uint32_t ord_cur = 0, ord_nxt = 0;
-    if (first + lane < N) ord_cur = P.fb.entries[ent_lo + first + lane].y;
-    if (first + stride + lane < N) ord_nxt = P.fb.entries[ent_lo + first + stride + lane].y;
+    if (first + lane < N) ord_cur = P.fb.entries[ent_lo + first + lane];
+    if (first + stride + lane < N) ord_nxt = P.fb.entries[ent_lo + first + stride + lane];
     RecA a_cur = zero_rec;
     if (first + lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
     for (uint32_t e0 = first; e0 < N; e0 += stride) {
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES) void k_tile_vis(TileParams P) {
         RecA a_nxt = zero_rec;
         if (e0 + stride + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
         uint32_t ord_nn = 0;
-        if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane].y;
+        if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
         Setup s;
         s.npx = 0;

@@ -44,7 +44,11 @@ struct mtr_device {
     uint32_t* bin_start = nullptr;
     uint32_t* seg_start = nullptr;
     uint32_t bin_cap = 0;
-    uint2* entries = nullptr;  // {record id, submission order}
+    uint32_t* entries = nullptr;  // submission order of every (triangle, bin) pair
+    // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
+    // two-pass queues and the bound is doubled for later frames
+    bool direct_enabled = true;
+    uint32_t qcap = 1024, scap = 128;
     Seg* segs = nullptr;
     uint32_t entry_cap = 0, seg_cap = 0;
     DMat* mats = nullptr;
@@ -117,7 +121,7 @@ struct mtr_frame {
     uint32_t shard_rank = 0, shard_world = 1;
     std::vector<Draw> draws;
     std::vector<DMat> mats_host;  // kept alive until the async upload has certainly been consumed
-    bool submitted = false, waited = false, all_opaque = true;
+    bool submitted = false, waited = false, all_opaque = true, force_two_pass = false, ran_direct = false;
     mtr_frame_stats stats{};
     hipEvent_t ev[MTR_STAGE_COUNT + 1] = {};
     bool have_events = false;
@@ -280,6 +284,14 @@ int32_t mtr_device_set_tile_mode(mtr_device* d, int32_t mode) {
     if (mode != MTR_TILE_AUTO && mode != MTR_TILE_ORDERED && mode != MTR_TILE_VISIBILITY)
         return fail(d, MTR_E_INVALID, "unknown tile mode");
     d->tile_mode = mode;
+    return MTR_OK;
+}
+
+int32_t mtr_device_set_binning(mtr_device* d, int32_t single_pass, uint32_t queue_capacity) {
+    if (!d) return MTR_E_INVALID;
+    if (queue_capacity && (queue_capacity < 64 || queue_capacity > 65536)) return fail(d, MTR_E_INVALID, "queue capacity out of range");
+    d->direct_enabled = single_pass != 0;
+    if (queue_capacity) { d->qcap = queue_capacity; d->scap = std::max<uint32_t>(16, queue_capacity / 8); }
     return MTR_OK;
 }
 
@@ -718,7 +730,15 @@ static int32_t run_frame(mtr_frame* f) {
         d->bin_cap = c0;
     }
     {
-        const uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2), s_need = std::max<uint64_t>(1u << 18, total_chunks * 8);
+        // direct mode: nbins bounded queues; the bound shrinks if the bin grid is so large that the queues would not
+        // be addressable with 32 bits
+        while ((uint64_t)nbins * d->qcap > 0xF0000000ull && d->qcap > 64) d->qcap /= 2;
+        f->ran_direct = d->direct_enabled && !f->force_two_pass;
+        uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2), s_need = std::max<uint64_t>(1u << 18, total_chunks * 8);
+        if (f->ran_direct) {
+            e_need = std::max<uint64_t>(e_need, (uint64_t)nbins * d->qcap);
+            s_need = std::max<uint64_t>(s_need, (uint64_t)nbins * d->scap);
+        }
         if (e_need > d->entry_cap || !d->entries) {
             HIPCHK(d, hipStreamSynchronize(d->stream));
             if ((rc = dev_grow(d, &d->entries, &d->entry_cap, std::min<uint64_t>(e_need, 0xFFFFFFF0ull)))) return rc;
@@ -772,6 +792,7 @@ static int32_t run_frame(mtr_frame* f) {
     fb.rec_cap = d->rec_cap; fb.entry_cap = d->entry_cap; fb.seg_cap = d->seg_cap;
     fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
     fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
+    fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
 
     if (d->profiling && !f->have_events) {
         for (auto& e : f->ev) HIPCHK(d, hipEventCreate(&e));
@@ -779,7 +800,7 @@ static int32_t run_frame(mtr_frame* f) {
     }
     const bool prof = d->profiling && f->have_events;
     HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), d->stream));
-    HIPCHK(d, hipMemsetAsync(d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
+    HIPCHK(d, hipMemsetAsync(fb.direct ? d->bin_fill : d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
     if (prof) HIPCHK(d, hipEventRecord(f->ev[0], d->stream));
     uint32_t chunk_base = 0;
     for (size_t di = 0; di < f->draws.size(); di++) {
@@ -798,9 +819,9 @@ static int32_t run_frame(mtr_frame* f) {
         chunk_base += gp.nchunks * dr.ninst;
     }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[1], d->stream));
-    mtr_launch_scan(fb, d->stream);
+    if (!fb.direct) mtr_launch_scan(fb, d->stream);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[2], d->stream));
-    mtr_launch_fill(fb, (uint32_t)total_chunks, d->stream);
+    if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, d->stream);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[3], d->stream));
     TileParams tp{};
     tp.fb = fb; tp.mats = d->mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
@@ -819,6 +840,7 @@ static int32_t run_frame(mtr_frame* f) {
         const uint32_t tk = f->stats.tile_kernel;
         f->stats = mtr_frame_stats{};
         f->stats.tile_kernel = tk;
+        f->stats.binning = f->ran_direct ? 1u : 2u;
     }
     f->stats.tris_in = tris_in;
     f->stats.width = f->w; f->stats.height = f->h; f->stats.nbins = nbins; f->stats.ndraws = (uint32_t)f->draws.size();
@@ -841,7 +863,7 @@ int32_t mtr_frame_wait(mtr_frame* f) {
     if (f->waited) return MTR_OK;
     int32_t rc = set_device(d);
     if (rc) return rc;
-    for (int attempt = 0; attempt < 4; attempt++) {
+    for (int attempt = 0; attempt < 5; attempt++) {
         uint32_t ctr[CTR_NUM];
         HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
@@ -849,6 +871,14 @@ int32_t mtr_frame_wait(mtr_frame* f) {
         for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[CTR_REC_SHARDS + k];
         f->stats.bin_entries = ctr[CTR_ENTRIES];
         f->stats.segments = ctr[CTR_SEGS];
+        if (f->ran_direct) {  // no scan in direct mode: the tile kernels counted the queues
+            f->stats.bin_entries = f->stats.segments = 0;
+            for (int k = 0; k < CTR_NSHARDS; k++) {
+                f->stats.bin_entries += ctr[CTR_ENT_SHARDS + k];
+                f->stats.segments += ctr[CTR_SEG_SHARDS + k];
+            }
+        }
+        f->stats.binning = f->ran_direct ? 1u : 2u;
         if (!ctr[CTR_OVERFLOW]) {
             if (d->profiling && f->have_events)
                 for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
@@ -856,6 +886,15 @@ int32_t mtr_frame_wait(mtr_frame* f) {
             return MTR_OK;
         }
         if (ctr[CTR_OVERFLOW] & 1u) return fail(d, MTR_E_OVERFLOW, "record capacity exceeded (internal bound violated)");
+        if (ctr[CTR_OVERFLOW] & 4u) {
+            // a bounded per-bin queue filled up: this frame takes the exact two-pass path, later frames get twice the bound
+            f->force_two_pass = true;
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+            if (d->qcap < 16384) { d->qcap *= 2; d->scap *= 2; }
+            else d->direct_enabled = false;
+            if ((rc = run_frame(f))) return rc;
+            continue;
+        }
         // bin queues too small: grow to what the scan measured and run the frame again
         const uint64_t e_need = (uint64_t)ctr[CTR_ENTRIES] + ctr[CTR_ENTRIES] / 4 + 1024;
         const uint64_t s_need = (uint64_t)ctr[CTR_SEGS] + ctr[CTR_SEGS] / 4 + 1024;
@@ -957,6 +996,13 @@ int32_t mtr_frame_read_bin_counts(mtr_frame* f, uint32_t* entries, uint32_t* seg
     HIPCHK(d, hipMemcpyAsync(bs.data(), d->bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(d, hipMemcpyAsync(ss.data(), d->seg_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(d, hipStreamSynchronize(d->stream));
+    if (f->ran_direct) {
+        std::vector<unsigned long long> bf(nbins);
+        HIPCHK(d, hipMemcpyAsync(bf.data(), d->bin_fill, nbins * 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));
+        for (size_t b = 0; b < nbins; b++) { entries[b] = (uint32_t)bf[b]; segments[b] = (uint32_t)(bf[b] >> 32); }
+        return MTR_OK;
+    }
     for (size_t b = 0; b < nbins; b++) { entries[b] = bs[b + 1] - bs[b]; segments[b] = ss[b + 1] - ss[b]; }
     return MTR_OK;
 }

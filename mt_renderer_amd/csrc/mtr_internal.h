@@ -77,7 +77,10 @@ struct Seg {             // 16 B
 };
 
 // counters[]: [1] entries, [2] segments, [3] overflow flags, [16..79] surviving-triangle count shards
-enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_REC_SHARDS = 16, CTR_NSHARDS = 64, CTR_NUM = 80 };
+// [80..143] / [144..207]: (triangle, bin) pair and segment count shards, filled by the tile kernels in direct mode
+// CTR_OVERFLOW bits: 1 record capacity (impossible), 2 two-pass queue capacity, 4 direct-mode per-bin queue full
+enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_REC_SHARDS = 16, CTR_NSHARDS = 64, CTR_ENT_SHARDS = 80,
+       CTR_SEG_SHARDS = 144, CTR_NUM = 208 };
 
 struct FrameBuffers {
     RecHdr* rec_hdr;
@@ -88,13 +91,31 @@ struct FrameBuffers {
     unsigned long long* bin_fill;
     uint32_t* bin_start;            // nbins + 1
     uint32_t* seg_start;            // nbins + 1
-    uint2* entries;                 // x = record id, y = submission order (chunk*128 + round*64 + rank)
+    uint32_t* entries;              // submission order of each (triangle, bin) pair: chunk*128 + index in the chunk's
+                                    // run; its record id is (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127)
     Seg* segs;
     uint32_t* counters;             // CTR_*
     uint32_t rec_cap, entry_cap, seg_cap;
     uint32_t W, H, nbx, nby;
     uint32_t shard_rank, shard_world;
+    // direct mode: single-pass binning into bounded per-bin queues (bin b owns entries[b*qcap ..) and
+    // segs[b*scap ..), filled through bin_fill); overflow raises CTR_OVERFLOW bit 2 and the host re-runs the frame
+    // with the exact two-pass (count, scan, fill) queues
+    uint32_t direct, qcap, scap;
 };
+
+// where bin b's queue lives, for both queue layouts
+__device__ __forceinline__ void bin_queue(const FrameBuffers& fb, uint32_t bin, uint32_t& ent_lo, uint32_t& n_ent,
+                                          uint32_t& seg_lo, uint32_t& n_seg) {
+    if (fb.direct) {
+        const unsigned long long f = fb.bin_fill[bin];
+        ent_lo = bin * fb.qcap; seg_lo = bin * fb.scap;
+        n_ent = min((uint32_t)f, fb.qcap); n_seg = min((uint32_t)(f >> 32), fb.scap);
+    } else {
+        ent_lo = fb.bin_start[bin]; n_ent = fb.bin_start[bin + 1] - ent_lo;
+        seg_lo = fb.seg_start[bin]; n_seg = fb.seg_start[bin + 1] - seg_lo;
+    }
+}
 
 struct GeomParams {
     const uint8_t* vbuf;

@@ -49,7 +49,7 @@ pub struct mtr_frame_stats {
     pub nbins: u32,
     pub ndraws: u32,
     pub tile_kernel: u32,
-    pub pad: u32,
+    pub binning: u32,
 }
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
 opaque!(mtr_device, mtr_texture, mtr_model, mtr_batch, mtr_frame);
@@ -62,6 +62,7 @@ extern "C" {
     pub fn mtr_last_error(dev: *const mtr_device) -> *const c_char;
     pub fn mtr_device_set_profiling(dev: *mut mtr_device, enable: i32) -> i32;
     pub fn mtr_device_set_tile_mode(dev: *mut mtr_device, mode: i32) -> i32;
+    pub fn mtr_device_set_binning(dev: *mut mtr_device, single_pass: i32, queue_capacity: u32) -> i32;
     pub fn mtr_frame_read_bin_counts(frame: *mut mtr_frame, entries: *mut u32, segments: *mut u32, nbins: usize) -> i32;
     pub fn mtr_texture_create(dev: *mut mtr_device, width: u32, height: u32, format: u32, data: *const c_void, len: usize,
                               out: *mut *mut mtr_texture) -> i32;

@@ -31,10 +31,16 @@ def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, sh
     material is opaque), require identical pixels, return the auto result."""
     from mt_renderer_amd import api
     if tile_mode is None:
+        # both tile kernels x both bin-queue builders (exact two-pass, single-pass bounded) must agree bit for bit
+        dev.set_binning(False)
         a = render_gpu(dev, w, h, draws, clear, clear_depth, shard, api.TILE_ORDERED)
+        dev.set_binning(True)
+        a2 = render_gpu(dev, w, h, draws, clear, clear_depth, shard, api.TILE_ORDERED)
         b = render_gpu(dev, w, h, draws, clear, clear_depth, shard, api.TILE_AUTO)
-        assert a[2]["tile_kernel"] == api.TILE_ORDERED
-        assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all(), "tile kernels disagree"
+        assert a[2]["tile_kernel"] == api.TILE_ORDERED and a[2]["binning"] == 2
+        for other in (a2, b):
+            assert (a[0] == other[0]).all() and (a[1].view(np.uint32) == other[1].view(np.uint32)).all(), "kernel variants disagree"
+            assert a[2]["bin_entries"] == other[2]["bin_entries"] and a[2]["tris_setup"] == other[2]["tris_setup"]
         return b
     dev.set_tile_mode(tile_mode)
     fr = api.Frame(dev, w, h, clear, clear_depth)

@@ -382,3 +382,30 @@ def test_opaque_textures_deferred_shading(gpu_device):
     vp = scene.reference_view_proj(w, h)
     M2 = scene.to_f32_colmajor(vp @ scene.mat_translate(-5.0, 0.0, 1.0 - 0.3) @ scene.mat_rot_x(0.5))
     _both(gpu_device, w, h, [dict(md=md, M=M2, palette=scene.bone_palette())])
+
+
+def test_single_pass_queue_overflow_falls_back(gpu_device):
+    """A bounded per-bin queue that fills up must not lose triangles: the frame is re-run with the exact two-pass
+    queues, and the bound doubles for the next frame."""
+    from mt_renderer_amd import api
+    rng = np.random.default_rng(7)
+    verts, idx = [], []
+    for q in range(400):  # 800 triangles inside one 16x16 bin
+        x0, y0, sz = rng.uniform(1, 10), rng.uniform(1, 10), rng.uniform(1.5, 4.0)
+        b = 4 * q
+        verts += [(x0, y0, .5 - q * 1e-4), (x0, y0 + sz, .5 - q * 1e-4), (x0 + sz, y0, .5 - q * 1e-4), (x0 + sz, y0 + sz, .5 - q * 1e-4)]
+        idx += [b, b + 1, b + 2, b + 3, 0xFFFF]
+    md = pixel_model([dict(verts=verts, indices=idx, topology=scene.TOPO_STRIP, debug_id=4)])
+    draws = [dict(md=md, M=pixel_to_ndc_matrix(32, 32))]
+    ref = render_oracle(32, 32, draws)
+    gpu_device.set_binning(True, 64)
+    try:
+        g = render_gpu(gpu_device, 32, 32, draws, tile_mode=api.TILE_AUTO)
+        assert g[2]["binning"] == 2  # fell back
+        assert_same(g, ref, "overflow fallback")
+        for _ in range(5):  # the bound doubles until the scene fits the single-pass queues
+            g = render_gpu(gpu_device, 32, 32, draws, tile_mode=api.TILE_AUTO)
+            assert_same(g, ref, "after growth")
+        assert g[2]["binning"] == 1
+    finally:
+        gpu_device.set_binning(True, 1024)
