@@ -24,6 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# HBM bytes per launch of the two heaviest kernels on the headline scene, from rocprofv3 PMC passes run separately
+# (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B,
+# MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_b_pmc_*.csv).
+TRAFFIC_TILE_VIS = 49067929     # k_tile_vis<false>: 2 x 15505.3 KB fetched + 16907.3 KB written (framebuffer = 16.6 MB)
+TRAFFIC_GEOM_DIRECT = 49235046  # k_geom<true>:      2 x 7351.5 KB fetched + 33378.1 KB written (records + bin queues)
 
 
 def algorithmic_bytes(md, width, height, npalettes, nbones=64):
@@ -142,8 +147,13 @@ def main():
     dom = max(stage_ms, key=lambda k: stage_ms[k])
     alg_bytes = algorithmic_bytes(md, W, H, 1)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+    kname = {"geom": "k_geom<%s>" % ("true" if stats["binning"] == 1 else "false"), "scan": "k_scan", "fill": "k_fill",
+             "tile": "k_tile_vis<false>" if stats["tile_kernel"] == 2 else "k_tile<false>"}[dom]
+    # HBM bytes of that kernel per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md); measured offline, see profiles/README.md
+    traffic = {"k_tile_vis<false>": TRAFFIC_TILE_VIS, "k_geom<true>": TRAFFIC_GEOM_DIRECT}.get(kname) if world == 1 else None
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 5),
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}}
 

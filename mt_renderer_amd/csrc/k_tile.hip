@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
         if (hi > (1ull << 32)) hi = 1ull << 32;
     }
 
+    if (lane == 0) bin_queue_done(P.fb, bin);
     // ---- write-out: the only framebuffer traffic of the frame ----
 #pragma unroll
     for (int i = 0; i < 4; i++) {

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES) void k_tile_vis(TileParams P) {
         ord_nxt = ord_nn;
     }
     __syncthreads();
+    if (threadIdx.x == 0) bin_queue_done(P.fb, bin);  // every wave has read its queue bounds by now
 
     // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame;
     //      one pixel per thread, rows of 16 pixels = 64 contiguous bytes ----

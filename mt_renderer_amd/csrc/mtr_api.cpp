@@ -48,6 +48,8 @@ struct mtr_device {
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
     // two-pass queues and the bound is doubled for later frames
     bool direct_enabled = true;
+    bool bin_fill_dirty = true;      // direct frames leave bin_fill zeroed (the tile kernels clean up); others do not
+    std::vector<DMat> mats_uploaded;  // what d->mats currently holds: steady-state frames skip the upload
     uint32_t qcap = 1024, scap = 128;
     Seg* segs = nullptr;
     uint32_t entry_cap = 0, seg_cap = 0;
@@ -728,6 +730,7 @@ static int32_t run_frame(mtr_frame* f) {
         if ((rc = dev_grow(d, &d->bin_start, &c2, nbins + 1))) return rc;
         if ((rc = dev_grow(d, &d->seg_start, &c3, nbins + 1))) return rc;
         d->bin_cap = c0;
+        d->bin_fill_dirty = true;
     }
     {
         // direct mode: nbins bounded queues; the bound shrinks if the bin grid is so large that the queues would not
@@ -781,9 +784,13 @@ static int32_t run_frame(mtr_frame* f) {
     if (mats.size() > d->mat_cap || !d->mats) {
         HIPCHK(d, hipStreamSynchronize(d->stream));
         if ((rc = dev_grow(d, &d->mats, &d->mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
+        d->mats_uploaded.clear();
     }
     // the material table is tiny; the copy is ordered on the stream before the kernels that read it
-    HIPCHK(d, hipMemcpyAsync(d->mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->stream));
+    if (mats.size() != d->mats_uploaded.size() || memcmp(mats.data(), d->mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0) {
+        HIPCHK(d, hipMemcpyAsync(d->mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->stream));
+        d->mats_uploaded = mats;
+    }
 
     FrameBuffers fb{};
     fb.rec_hdr = d->rec_hdr; fb.rec_a = d->rec_a; fb.rec_b = d->rec_b; fb.chunk_info = d->chunk_info;
@@ -800,7 +807,13 @@ static int32_t run_frame(mtr_frame* f) {
     }
     const bool prof = d->profiling && f->have_events;
     HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), d->stream));
-    HIPCHK(d, hipMemsetAsync(fb.direct ? d->bin_fill : d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
+    if (!fb.direct) {
+        HIPCHK(d, hipMemsetAsync(d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
+        d->bin_fill_dirty = true;
+    } else if (d->bin_fill_dirty) {
+        HIPCHK(d, hipMemsetAsync(d->bin_fill, 0, (size_t)d->bin_cap * sizeof(unsigned long long), d->stream));
+        d->bin_fill_dirty = false;
+    }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[0], d->stream));
     uint32_t chunk_base = 0;
     for (size_t di = 0; di < f->draws.size(); di++) {
@@ -997,8 +1010,8 @@ int32_t mtr_frame_read_bin_counts(mtr_frame* f, uint32_t* entries, uint32_t* seg
     HIPCHK(d, hipMemcpyAsync(ss.data(), d->seg_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(d, hipStreamSynchronize(d->stream));
     if (f->ran_direct) {
-        std::vector<unsigned long long> bf(nbins);
-        HIPCHK(d, hipMemcpyAsync(bf.data(), d->bin_fill, nbins * 8, hipMemcpyDeviceToHost, d->stream));
+        std::vector<unsigned long long> bf(nbins);  // the tile kernels moved the counts here when they cleaned bin_fill
+        HIPCHK(d, hipMemcpyAsync(bf.data(), d->bin_count, nbins * 8, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
         for (size_t b = 0; b < nbins; b++) { entries[b] = (uint32_t)bf[b]; segments[b] = (uint32_t)(bf[b] >> 32); }
         return MTR_OK;

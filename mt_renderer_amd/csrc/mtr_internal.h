@@ -104,10 +104,21 @@ struct FrameBuffers {
     uint32_t direct, qcap, scap;
 };
 
+// direct mode: the bin's workgroup is the only consumer of bin_fill[bin]; one thread parks the count in bin_count
+// (statistics hook) and zeroes the fill word, so the next frame needs no memset.  Call after every wave of the
+// workgroup has read its queue bounds.
+__device__ __forceinline__ void bin_queue_done(const FrameBuffers& fb, uint32_t bin) {
+    if (fb.direct) {
+        fb.bin_count[bin] = fb.bin_fill[bin];
+        fb.bin_fill[bin] = 0ull;
+    }
+}
+
 // where bin b's queue lives, for both queue layouts
 __device__ __forceinline__ void bin_queue(const FrameBuffers& fb, uint32_t bin, uint32_t& ent_lo, uint32_t& n_ent,
                                           uint32_t& seg_lo, uint32_t& n_seg) {
     if (fb.direct) {
+        // every lane of the bin's workgroup reads the same word; the caller cleans it afterwards (bin_queue_done)
         const unsigned long long f = fb.bin_fill[bin];
         ent_lo = bin * fb.qcap; seg_lo = bin * fb.scap;
         n_ent = min((uint32_t)f, fb.qcap); n_seg = min((uint32_t)(f >> 32), fb.scap);
