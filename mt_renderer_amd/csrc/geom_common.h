@@ -224,6 +224,69 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// One round = up to 64 records of a chunk's run, lane = record.  A record whose bin rectangle holds more
+// than MTR_WIDE_BINS bins (a big triangle) is "wide": walking its bins with one lane would serialise the
+// wave (a 12-triangle cube cost 1 ms that way), so wide records are emitted cooperatively, lane = bin.
+// To keep submission order exact a wide record splits the round: the records before it are grouped and
+// emitted first, then the wide record, then the rest.  Every segment is keyed by the submission order of
+// its first entry, which makes segment keys unique and totally ordered per bin.
+//   on_groups(act_sub): bin grouping of the lanes with act_sub set;  on_wide(wl): emit the record of lane wl.
+// ---------------------------------------------------------------------------------------------
+#define MTR_WIDE_BINS 16
+
+template <class FG, class FW>
+__device__ __forceinline__ void walk_round(RecHdr h, bool act, uint32_t lane, FG on_groups, FW on_wide) {
+    const uint32_t nb = act ? (uint32_t)(h.bx1 - h.bx0 + 1) * (uint32_t)(h.by1 - h.by0 + 1) : 0u;
+    uint64_t mw = __ballot(nb > MTR_WIDE_BINS);
+    if (!mw) {
+        on_groups(act);
+        return;
+    }
+    uint32_t lo = 0;
+    for (;;) {
+        const uint32_t wl = mw ? __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)mw) - 1) : 64u;
+        on_groups(act && lane >= lo && lane < wl && nb <= MTR_WIDE_BINS);
+        if (wl == 64) break;
+        on_wide(wl);
+        mw &= mw - 1;
+        lo = wl + 1;
+    }
+}
+
+// bins of a wide record: lane i of a 64-lane step serves bin number `i` of the rectangle (row-major)
+template <class F>
+__device__ __forceinline__ void for_each_wide_bin(RecHdr hw, uint32_t lane, uint32_t nbx, uint32_t rank, uint32_t world, F f) {
+    const uint32_t w = (uint32_t)(hw.bx1 - hw.bx0 + 1), n = w * (uint32_t)(hw.by1 - hw.by0 + 1);
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t bin = (hw.by0 + i / w) * nbx + hw.bx0 + i % w;
+        if (bin_owned(bin, rank, world)) f(bin);
+    }
+}
+
+__device__ __forceinline__ RecHdr hdr_of_lane(RecHdr h, uint32_t wl) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)h.bx0 | ((uint32_t)h.by0 << 16)), wl);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)((uint32_t)h.bx1 | ((uint32_t)h.by1 << 16)), wl);
+    RecHdr r = {(uint16_t)(lo & 0xffff), (uint16_t)(lo >> 16), (uint16_t)(hi & 0xffff), (uint16_t)(hi >> 16)};
+    return r;
+}
+
+// count pass of the two-pass path (k_geom<false>): one non-returning atomic per (wave, bin) group / wide bin
+__device__ __forceinline__ void count_bins(const FrameBuffers& fb, RecHdr h, bool act, uint32_t lane) {
+    walk_round(
+        h, act, lane,
+        [&](bool act_sub) {
+            for_each_bin_group(h, act_sub, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool hit) {
+                if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
+                    atomicAdd(&fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
+            });
+        },
+        [&](uint32_t wl) {
+            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world,
+                              [&](uint32_t bin) { atomicAdd(&fb.bin_count[bin], 1ull | (1ull << 32)); });
+        });
+}
+
+// ---------------------------------------------------------------------------------------------
 // Hands one round of records (lane = record `round*64 + lane` of chunk `gid`'s run) to the bin queues.
 // The (bin, lanes) groups are enumerated first; queue space for up to 64 groups is then reserved by ONE
 // wave-wide returning atomic (lane g reserves for group g), so the atomic round trip is paid once per
@@ -233,47 +296,56 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
 // ---------------------------------------------------------------------------------------------
 template <bool DIRECT>
 __device__ __forceinline__ void emit_bins(const FrameBuffers& fb, RecHdr h, bool act, uint32_t gid, uint32_t round, uint32_t lane) {
-    uint32_t gbin = 0, ng = 0;
-    uint64_t gmask = 0;
-    auto flush = [&]() {
-        if (ng == 0) return;
-        unsigned long long t = 0;
-        uint32_t qbase = 0, sbase = 0;
-        if (lane < ng) {
-            t = atomicAdd(&fb.bin_fill[gbin], (unsigned long long)__popcll(gmask) | (1ull << 32));
-            if (DIRECT) { qbase = gbin * fb.qcap; sbase = gbin * fb.scap; }
-            else { qbase = fb.bin_start[gbin]; sbase = fb.seg_start[gbin]; }
-        }
-        for (uint32_t gi = 0; gi < ng; gi++) {
-            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gmask >> 32), gi) << 32) |
-                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gmask, gi);
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, gi);
-            const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), gi);
-            const uint32_t qb = (uint32_t)__builtin_amdgcn_readlane((int)qbase, gi);
-            const uint32_t sb = (uint32_t)__builtin_amdgcn_readlane((int)sbase, gi);
-            const uint32_t cnt = (uint32_t)__popcll(m);
-            const bool fits = !DIRECT || (off + cnt <= fb.qcap && si < fb.scap);
-            if ((m >> lane) & 1ull) {
-                const bool leader = lane == (uint32_t)__ffsll((long long)m) - 1;
-                if (fits) {
-                    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    fb.entries[qb + off + rank] = gid * 128u + round * 64u + lane;
-                    if (leader) {
-                        Seg sg = {gid * 2u + round, off, cnt, 0u};
-                        fb.segs[sb + si] = sg;
-                    }
-                } else if (leader) {
-                    atomicOr(&fb.counters[CTR_OVERFLOW], 4u);
-                }
+    const uint32_t ord0 = gid * 128u + round * 64u;  // submission order of lane 0's record
+    auto put = [&](uint32_t bin, unsigned long long t, uint32_t cnt, uint32_t rank, uint32_t order, bool leader, uint32_t key) {
+        const uint32_t off = (uint32_t)t, si = (uint32_t)(t >> 32);
+        const uint32_t qb = DIRECT ? bin * fb.qcap : fb.bin_start[bin];
+        const uint32_t sb = DIRECT ? bin * fb.scap : fb.seg_start[bin];
+        if (!DIRECT || (off + cnt <= fb.qcap && si < fb.scap)) {
+            fb.entries[qb + off + rank] = order;
+            if (leader) {
+                Seg sg = {key, off, cnt, 0u};
+                fb.segs[sb + si] = sg;
             }
+        } else if (leader) {
+            atomicOr(&fb.counters[CTR_OVERFLOW], 4u);
         }
-        ng = 0;
     };
-    for_each_bin_group(h, act, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool) {
-        if (lane == ng) { gbin = bin; gmask = m; }
-        if (++ng == 64) flush();
-    });
-    flush();
+    walk_round(
+        h, act, lane,
+        [&](bool act_sub) {
+            uint32_t gbin = 0, ng = 0;
+            uint64_t gmask = 0;
+            auto flush = [&]() {
+                if (ng == 0) return;
+                unsigned long long t = 0;
+                if (lane < ng) t = atomicAdd(&fb.bin_fill[gbin], (unsigned long long)__popcll(gmask) | (1ull << 32));
+                for (uint32_t gi = 0; gi < ng; gi++) {
+                    const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gmask >> 32), gi) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gmask, gi);
+                    const unsigned long long tg = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(t >> 32), gi) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)t, gi);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)gbin, gi);
+                    if ((m >> lane) & 1ull) {
+                        const uint32_t first = (uint32_t)__ffsll((long long)m) - 1;
+                        put(b, tg, (uint32_t)__popcll(m), (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), ord0 + lane, lane == first,
+                            ord0 + first);
+                    }
+                }
+                ng = 0;
+            };
+            for_each_bin_group(h, act_sub, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool) {
+                if (lane == ng) { gbin = bin; gmask = m; }
+                if (++ng == 64) flush();
+            });
+            flush();
+        },
+        [&](uint32_t wl) {
+            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin) {
+                const unsigned long long t = atomicAdd(&fb.bin_fill[bin], 1ull | (1ull << 32));
+                put(bin, t, 1u, 0u, ord0 + wl, true, ord0 + wl);
+            });
+        });
 }
 
 }  // namespace mtr

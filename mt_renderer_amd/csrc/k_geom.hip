@@ -123,7 +123,10 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
 }
 
 template <bool DIRECT>
-__global__ __launch_bounds__(256) void k_geom(GeomParams P) {
+#ifndef GEOM_OCC
+#define GEOM_OCC 4  // waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
     const uint32_t lane = threadIdx.x & 63;
@@ -247,7 +250,11 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
     // texcoord planes are only read by textured materials: do not spend 48 B/triangle of HBM writes otherwise
-    const bool want_b = pr.has_uv && P.mats[mat].shader == MTR_SH_TEXTURED;
+    const DMat dmat = P.mats[mat];  // wave-uniform
+    const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
+    // the fragment stage finds the source colour / shader class in the record itself: no dependent material lookup
+    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8);
+    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = dmat.shader | (dmat.blend << 8);
     if (n_out >= 1) {
         P.fb.rec_a[base + rank] = r0.a;
         P.fb.rec_hdr[base + rank] = r0.h;
@@ -275,11 +282,7 @@ __global__ __launch_bounds__(256) void k_geom(GeomParams P) {
         if (DIRECT) {
             emit_bins<true>(P.fb, h, act, gid, round, lane);
         } else {
-            for_each_bin_group(h, act, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world,
-                               [&](uint32_t bin, uint64_t m, bool hit) {
-                                   if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
-                                       atomicAdd(&P.fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
-                               });
+            count_bins(P.fb, h, act, lane);
         }
     }
 }

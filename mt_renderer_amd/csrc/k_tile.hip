@@ -51,7 +51,7 @@ template <bool TEX>
 __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriC& t, TriX* x,
                                             int4& chi, uint32_t& submask) {
     const RecA a = P.fb.rec_a[r];
-    const DMat mat = P.mats[a.mat];
+    const uint32_t mshader = a.pad1 & 0xffu, mblend = a.pad1 >> 8;
     const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
     const long long A2 = (long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]);
     const int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
@@ -73,15 +73,15 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
         Clo[i] = (int32_t)(uint32_t)(unsigned long long)C;
         Chi[i] = (int32_t)(C >> 32);
     }
-    if (TEX && mat.shader == MTR_SH_TEXTURED) flags |= TF_TEX;
-    if (mat.blend) flags |= TF_BLEND;
+    if (TEX && mshader == MTR_SH_TEXTURED) flags |= TF_TEX;
+    if (mblend) flags |= TF_BLEND;
     t.A0 = A[0]; t.B0 = B[0]; t.C0 = Clo[0];
     t.A1 = A[1]; t.B1 = B[1]; t.C1 = Clo[1];
     t.A2 = A[2]; t.B2 = B[2]; t.C2 = Clo[2];
     t.flags = flags;
     t.z0 = a.z0; t.dz1 = a.z1 - a.z0; t.dz2 = a.z2 - a.z0;
     t.rcpA = 1.0f / (float)A2;
-    t.rgba8 = mat.rgba8;
+    t.rgba8 = a.pad0;
     t.pad = 0;
     chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
     // sub-tiles (8x8 px) of this bin touched by the pixel-centre bbox: bit = sy*2 + sx
@@ -94,7 +94,8 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
         if (py1 >= 8) sm |= colbits << 2;
     }
     submask = sm;
-    if (TEX && mat.shader == MTR_SH_TEXTURED) {
+    if (TEX && mshader == MTR_SH_TEXTURED) {
+        const DMat mat = P.mats[a.mat];
         const RecB b = P.fb.rec_b[r];
         x->iw0 = b.iw0; x->diw1 = b.iw1 - b.iw0; x->diw2 = b.iw2 - b.iw0;
         x->up0 = b.up0; x->dup1 = b.up1 - b.up0; x->dup2 = b.up2 - b.up0;

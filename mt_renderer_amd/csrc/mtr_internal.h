@@ -59,7 +59,7 @@ struct RecA {            // 48 B: what coverage + depth need
     float z0, z1;
     float z2;
     uint32_t mat;
-    uint32_t pad0, pad1;
+    uint32_t pad0, pad1;  // pad0 = material rgba8 (debug / overlay colour), pad1 = shader | blend << 8
 };
 struct RecB {            // 48 B: perspective-correct texcoords (textured primitives only)
     float iw0, iw1, iw2, up0;

@@ -1,0 +1,13 @@
+set -e
+cd $GRAFT_REPO_ROOT/mt_renderer_amd/csrc
+cp ../../tools/abl/k_tile_vis_abl.hip ./k_tile_vis_abl.hip
+for v in "VIS_LANE_MAX=32" "VIS_LANE_MAX=32 -DABL_NO_P2" "VIS_LANE_MAX=64" "VIS_LANE_MAX=256" "VIS_LANE_MAX=256 -DABL_NO_P2"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -D$v -c k_tile_vis_abl.hip -o k_tile_vis.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr.so k_geom.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o
+  cd ../..
+  echo "variant=$v" >> gpurun_out/abl.log
+  timeout -k 10 200 python tools/tile_floor.py 2>/dev/null | grep "C2 mesh50k {" >> gpurun_out/abl.log
+  timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('HL', d['ms_per_step'], d['roofline']['stage_ms'])" >> gpurun_out/abl.log
+  cd mt_renderer_amd/csrc
+done
+rm -f k_tile_vis_abl.hip
