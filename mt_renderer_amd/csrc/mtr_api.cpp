@@ -25,15 +25,10 @@ struct ColorDepth {
 
 }  // namespace
 
-struct mtr_device {
-    int hip_dev = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    bool profiling = false;
-    int tile_mode = MTR_TILE_AUTO;
-    std::string err;
-    // grow-only intermediate buffers, shared by every frame of this device (frames execute in
-    // stream order, so a later frame never overlaps an earlier one's use of them)
+// Intermediate buffers of one frame in flight.  The device keeps two slots and two internal streams (geometry,
+// tile): frame k+1's geometry runs while frame k's tile kernel is still rasterising, which is what keeps a
+// latency-bound pipeline busy (DESIGN.md "frames in flight").  Grow-only.
+struct Slot {
     RecHdr* rec_hdr = nullptr;
     RecA* rec_a = nullptr;
     RecB* rec_b = nullptr;
@@ -45,16 +40,30 @@ struct mtr_device {
     uint32_t* seg_start = nullptr;
     uint32_t bin_cap = 0;
     uint32_t* entries = nullptr;  // submission order of every (triangle, bin) pair
-    // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
-    // two-pass queues and the bound is doubled for later frames
-    bool direct_enabled = true;
-    bool bin_fill_dirty = true;      // direct frames leave bin_fill zeroed (the tile kernels clean up); others do not
-    std::vector<DMat> mats_uploaded;  // what d->mats currently holds: steady-state frames skip the upload
-    uint32_t qcap = 1024, scap = 128;
     Seg* segs = nullptr;
     uint32_t entry_cap = 0, seg_cap = 0;
     DMat* mats = nullptr;
     uint32_t mat_cap = 0;
+    bool bin_fill_dirty = true;      // direct frames leave bin_fill zeroed (the tile kernels clean up); others do not
+    std::vector<DMat> mats_uploaded;  // what `mats` currently holds: steady-state frames skip the upload
+    hipEvent_t tile_done = nullptr;   // recorded after the tile kernel of the last frame that used this slot
+    bool used = false;
+};
+
+struct mtr_device {
+    int hip_dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool profiling = false;
+    int tile_mode = MTR_TILE_AUTO;
+    std::string err;
+    Slot slots[2];
+    uint32_t frame_counter = 0;
+    hipStream_t s_geom = nullptr, s_tile = nullptr;  // internal streams; `stream` joins them at every submit
+    // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
+    // two-pass queues and the bound is doubled for later frames
+    bool direct_enabled = true;
+    uint32_t qcap = 1024, scap = 128;
     std::vector<ColorDepth> free_fb;
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
 };
@@ -128,6 +137,9 @@ struct mtr_frame {
     hipEvent_t ev[MTR_STAGE_COUNT + 1] = {};
     bool have_events = false;
     float ms[MTR_STAGE_COUNT] = {};
+    int slot = 0;
+    uint64_t min_entries = 0, min_segs = 0;  // queue sizes measured by a previous, overflowed attempt
+    hipEvent_t ev_geom = nullptr, ev_done = nullptr;  // geometry finished / framebuffer complete
 };
 
 namespace {
@@ -255,6 +267,9 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
         HIPCHK(nullptr, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         d->own_stream = true;
     }
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_geom, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_tile, hipStreamNonBlocking));
+    for (Slot& sl : d->slots) HIPCHK(nullptr, hipEventCreateWithFlags(&sl.tile_done, hipEventDisableTiming));
     *out = d.release();
     return MTR_OK;
 }
@@ -267,16 +282,23 @@ void mtr_device_destroy(mtr_device* d) {
     if (!d) return;
     (void)hipSetDevice(d->hip_dev);
     (void)hipStreamSynchronize(d->stream);
+    if (d->s_geom) (void)hipStreamSynchronize(d->s_geom);
+    if (d->s_tile) (void)hipStreamSynchronize(d->s_tile);
     if (d->cube) mtr_model_destroy(d->cube);
     for (auto& f : d->free_fb) {
         (void)hipFree(f.color);
         (void)hipFree(f.depth);
         (void)hipFree(f.counters);
     }
-    void* ptrs[] = {d->rec_hdr, d->rec_a, d->rec_b, d->chunk_info, d->bin_count, d->bin_fill,
-                    d->bin_start, d->seg_start, d->entries, d->segs, d->mats};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    for (Slot& sl : d->slots) {
+        void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
+                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (sl.tile_done) (void)hipEventDestroy(sl.tile_done);
+    }
+    if (d->s_geom) (void)hipStreamDestroy(d->s_geom);
+    if (d->s_tile) (void)hipStreamDestroy(d->s_tile);
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -591,6 +613,8 @@ void mtr_frame_destroy(mtr_frame* f) {
     if (f->have_events)
         for (auto& e : f->ev)
             if (e) (void)hipEventDestroy(e);
+    if (f->ev_geom) (void)hipEventDestroy(f->ev_geom);
+    if (f->ev_done) (void)hipEventDestroy(f->ev_done);
     // stream order protects the buffers: a later frame's kernels run after this frame's
     d->free_fb.push_back(f->fb);
     delete f;
@@ -708,29 +732,36 @@ static int32_t run_frame(mtr_frame* f) {
         tris_in += m->ntris_visible * dr.ninst;
     }
     if (total_chunks > 0x3FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
+    // this frame's slot: the other slot may still be feeding the previous frame's tile kernel
+    f->slot = (int)(d->frame_counter++ & 1u);
+    Slot& sl = d->slots[f->slot];
+    if (!f->ev_done) {
+        HIPCHK(d, hipEventCreateWithFlags(&f->ev_geom, hipEventDisableTiming));
+        HIPCHK(d, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
+    }
     const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
     if (rec_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many triangles in one frame");
-    if (rec_need > d->rec_cap || !d->rec_a) {
+    if (rec_need > sl.rec_cap || !sl.rec_a) {
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        uint32_t c0 = d->rec_cap, c1 = d->rec_cap, c2 = d->rec_cap;
-        if ((rc = dev_grow(d, &d->rec_hdr, &c0, rec_need))) return rc;
-        if ((rc = dev_grow(d, &d->rec_a, &c1, rec_need))) return rc;
-        if ((rc = dev_grow(d, &d->rec_b, &c2, rec_need))) return rc;
-        d->rec_cap = c0;
+        uint32_t c0 = sl.rec_cap, c1 = sl.rec_cap, c2 = sl.rec_cap;
+        if ((rc = dev_grow(d, &sl.rec_hdr, &c0, rec_need))) return rc;
+        if ((rc = dev_grow(d, &sl.rec_a, &c1, rec_need))) return rc;
+        if ((rc = dev_grow(d, &sl.rec_b, &c2, rec_need))) return rc;
+        sl.rec_cap = c0;
     }
-    if (total_chunks > d->chunk_cap || !d->chunk_info) {
+    if (total_chunks > sl.chunk_cap || !sl.chunk_info) {
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        if ((rc = dev_grow(d, &d->chunk_info, &d->chunk_cap, total_chunks))) return rc;
+        if ((rc = dev_grow(d, &sl.chunk_info, &sl.chunk_cap, total_chunks))) return rc;
     }
-    if (nbins + 1 > d->bin_cap || !d->bin_count) {
+    if (nbins + 1 > sl.bin_cap || !sl.bin_count) {
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        uint32_t c0 = d->bin_cap, c1 = d->bin_cap, c2 = d->bin_cap, c3 = d->bin_cap;
-        if ((rc = dev_grow(d, &d->bin_count, &c0, nbins + 1))) return rc;
-        if ((rc = dev_grow(d, &d->bin_fill, &c1, nbins + 1))) return rc;
-        if ((rc = dev_grow(d, &d->bin_start, &c2, nbins + 1))) return rc;
-        if ((rc = dev_grow(d, &d->seg_start, &c3, nbins + 1))) return rc;
-        d->bin_cap = c0;
-        d->bin_fill_dirty = true;
+        uint32_t c0 = sl.bin_cap, c1 = sl.bin_cap, c2 = sl.bin_cap, c3 = sl.bin_cap;
+        if ((rc = dev_grow(d, &sl.bin_count, &c0, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &sl.bin_fill, &c1, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &sl.bin_start, &c2, nbins + 1))) return rc;
+        if ((rc = dev_grow(d, &sl.seg_start, &c3, nbins + 1))) return rc;
+        sl.bin_cap = c0;
+        sl.bin_fill_dirty = true;
     }
     {
         // direct mode: nbins bounded queues; the bound shrinks if the bin grid is so large that the queues would not
@@ -738,17 +769,19 @@ static int32_t run_frame(mtr_frame* f) {
         while ((uint64_t)nbins * d->qcap > 0xF0000000ull && d->qcap > 64) d->qcap /= 2;
         f->ran_direct = d->direct_enabled && !f->force_two_pass;
         uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2), s_need = std::max<uint64_t>(1u << 18, total_chunks * 8);
+        e_need = std::max<uint64_t>(e_need, f->min_entries);
+        s_need = std::max<uint64_t>(s_need, f->min_segs);
         if (f->ran_direct) {
             e_need = std::max<uint64_t>(e_need, (uint64_t)nbins * d->qcap);
             s_need = std::max<uint64_t>(s_need, (uint64_t)nbins * d->scap);
         }
-        if (e_need > d->entry_cap || !d->entries) {
+        if (e_need > sl.entry_cap || !sl.entries) {
             HIPCHK(d, hipStreamSynchronize(d->stream));
-            if ((rc = dev_grow(d, &d->entries, &d->entry_cap, std::min<uint64_t>(e_need, 0xFFFFFFF0ull)))) return rc;
+            if ((rc = dev_grow(d, &sl.entries, &sl.entry_cap, std::min<uint64_t>(e_need, 0xFFFFFFF0ull)))) return rc;
         }
-        if (s_need > d->seg_cap || !d->segs) {
+        if (s_need > sl.seg_cap || !sl.segs) {
             HIPCHK(d, hipStreamSynchronize(d->stream));
-            if ((rc = dev_grow(d, &d->segs, &d->seg_cap, std::min<uint64_t>(s_need, 0xFFFFFFF0ull)))) return rc;
+            if ((rc = dev_grow(d, &sl.segs, &sl.seg_cap, std::min<uint64_t>(s_need, 0xFFFFFFF0ull)))) return rc;
         }
     }
     // ---- material table ----
@@ -781,22 +814,22 @@ static int32_t run_frame(mtr_frame* f) {
                 mats.push_back(dm);
             }
     }
-    if (mats.size() > d->mat_cap || !d->mats) {
+    if (mats.size() > sl.mat_cap || !sl.mats) {
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        if ((rc = dev_grow(d, &d->mats, &d->mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
-        d->mats_uploaded.clear();
+        if ((rc = dev_grow(d, &sl.mats, &sl.mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
+        sl.mats_uploaded.clear();
     }
     // the material table is tiny; the copy is ordered on the stream before the kernels that read it
-    if (mats.size() != d->mats_uploaded.size() || memcmp(mats.data(), d->mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0) {
-        HIPCHK(d, hipMemcpyAsync(d->mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->stream));
-        d->mats_uploaded = mats;
+    if (mats.size() != sl.mats_uploaded.size() || memcmp(mats.data(), sl.mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0) {
+        HIPCHK(d, hipMemcpyAsync(sl.mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->s_geom));
+        sl.mats_uploaded = mats;
     }
 
     FrameBuffers fb{};
-    fb.rec_hdr = d->rec_hdr; fb.rec_a = d->rec_a; fb.rec_b = d->rec_b; fb.chunk_info = d->chunk_info;
-    fb.bin_count = d->bin_count; fb.bin_fill = d->bin_fill; fb.bin_start = d->bin_start; fb.seg_start = d->seg_start;
-    fb.entries = d->entries; fb.segs = d->segs; fb.counters = f->fb.counters;
-    fb.rec_cap = d->rec_cap; fb.entry_cap = d->entry_cap; fb.seg_cap = d->seg_cap;
+    fb.rec_hdr = sl.rec_hdr; fb.rec_a = sl.rec_a; fb.rec_b = sl.rec_b; fb.chunk_info = sl.chunk_info;
+    fb.bin_count = sl.bin_count; fb.bin_fill = sl.bin_fill; fb.bin_start = sl.bin_start; fb.seg_start = sl.seg_start;
+    fb.entries = sl.entries; fb.segs = sl.segs; fb.counters = f->fb.counters;
+    fb.rec_cap = sl.rec_cap; fb.entry_cap = sl.entry_cap; fb.seg_cap = sl.seg_cap;
     fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
     fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
     fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
@@ -806,15 +839,18 @@ static int32_t run_frame(mtr_frame* f) {
         f->have_events = true;
     }
     const bool prof = d->profiling && f->have_events;
-    HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), d->stream));
+    hipStream_t sg = d->s_geom, st = d->s_tile;
+    // slot reuse: the geometry of this frame overwrites what the tile kernel of frame k-2 read
+    if (sl.used) HIPCHK(d, hipStreamWaitEvent(sg, sl.tile_done, 0));
+    HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), sg));
     if (!fb.direct) {
-        HIPCHK(d, hipMemsetAsync(d->bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), d->stream));
-        d->bin_fill_dirty = true;
-    } else if (d->bin_fill_dirty) {
-        HIPCHK(d, hipMemsetAsync(d->bin_fill, 0, (size_t)d->bin_cap * sizeof(unsigned long long), d->stream));
-        d->bin_fill_dirty = false;
+        HIPCHK(d, hipMemsetAsync(sl.bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), sg));
+        sl.bin_fill_dirty = true;
+    } else if (sl.bin_fill_dirty) {
+        HIPCHK(d, hipMemsetAsync(sl.bin_fill, 0, (size_t)sl.bin_cap * sizeof(unsigned long long), sg));
+        sl.bin_fill_dirty = false;
     }
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[0], d->stream));
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[0], sg));
     uint32_t chunk_base = 0;
     for (size_t di = 0; di < f->draws.size(); di++) {
         Draw& dr = f->draws[di];
@@ -827,17 +863,19 @@ static int32_t run_frame(mtr_frame* f) {
         memcpy(gp.vp, dr.vp, sizeof gp.vp);
         gp.chunk_base = chunk_base; gp.mat_base = mat_base[di]; gp.mat_inst_stride = mat_stride[di];
         gp.fb = fb;
-        gp.mats = d->mats;
-        mtr_launch_geom(gp, d->stream);
+        gp.mats = sl.mats;
+        mtr_launch_geom(gp, sg);
         chunk_base += gp.nchunks * dr.ninst;
     }
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[1], d->stream));
-    if (!fb.direct) mtr_launch_scan(fb, d->stream);
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[2], d->stream));
-    if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, d->stream);
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[3], d->stream));
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[1], sg));
+    if (!fb.direct) mtr_launch_scan(fb, sg);
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[2], sg));
+    if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, sg);
+    HIPCHK(d, hipEventRecord(f->ev_geom, sg));
+    HIPCHK(d, hipStreamWaitEvent(st, f->ev_geom, 0));
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[3], st));
     TileParams tp{};
-    tp.fb = fb; tp.mats = d->mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
+    tp.fb = fb; tp.mats = sl.mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
     bool any_textured = false;
     for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
@@ -845,9 +883,14 @@ static int32_t run_frame(mtr_frame* f) {
     // per-pixel (min z, latest) reduction and the visibility-key kernel applies; otherwise blend order matters
     const bool use_vis = f->all_opaque && d->tile_mode != MTR_TILE_ORDERED;
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : MTR_TILE_ORDERED;
-    if (use_vis) mtr_launch_tile_vis(tp, any_textured, d->stream);
-    else mtr_launch_tile(tp, any_textured, d->stream);
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[4], d->stream));
+    if (use_vis) mtr_launch_tile_vis(tp, any_textured, st);
+    else mtr_launch_tile(tp, any_textured, st);
+    if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
+    HIPCHK(d, hipEventRecord(sl.tile_done, st));
+    HIPCHK(d, hipEventRecord(f->ev_done, st));
+    sl.used = true;
+    // the device's public stream (read-backs, shard packing, the caller's own work) sees the framebuffer complete
+    HIPCHK(d, hipStreamWaitEvent(d->stream, f->ev_done, 0));
     HIPCHK(d, hipGetLastError());
     {
         const uint32_t tk = f->stats.tile_kernel;
@@ -912,8 +955,8 @@ int32_t mtr_frame_wait(mtr_frame* f) {
         const uint64_t e_need = (uint64_t)ctr[CTR_ENTRIES] + ctr[CTR_ENTRIES] / 4 + 1024;
         const uint64_t s_need = (uint64_t)ctr[CTR_SEGS] + ctr[CTR_SEGS] / 4 + 1024;
         if (e_need > 0xFFFFFFF0ull || s_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "bin queues exceed 2^32 entries");
-        if (e_need > d->entry_cap && (rc = dev_grow(d, &d->entries, &d->entry_cap, e_need))) return rc;
-        if (s_need > d->seg_cap && (rc = dev_grow(d, &d->segs, &d->seg_cap, s_need))) return rc;
+        f->min_entries = e_need;  // run_frame grows the queues of the slot it picks
+        f->min_segs = s_need;
         if ((rc = run_frame(f))) return rc;
     }
     return fail(d, MTR_E_OVERFLOW, "bin queues still overflow after growing");
@@ -1003,15 +1046,16 @@ int32_t mtr_frame_read_bin_counts(mtr_frame* f, uint32_t* entries, uint32_t* seg
     if (!f || !entries || !segments) return MTR_E_INVALID;
     mtr_device* d = f->dev;
     if (nbins != f->stats.nbins) return fail(d, MTR_E_INVALID, "nbins mismatch");
+    Slot& sl = d->slots[f->slot];
     int32_t rc = mtr_frame_wait(f);
     if (rc) return rc;
     std::vector<uint32_t> bs(nbins + 1), ss(nbins + 1);
-    HIPCHK(d, hipMemcpyAsync(bs.data(), d->bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(d, hipMemcpyAsync(ss.data(), d->seg_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipMemcpyAsync(bs.data(), sl.bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(d, hipMemcpyAsync(ss.data(), sl.seg_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, d->stream));
     HIPCHK(d, hipStreamSynchronize(d->stream));
     if (f->ran_direct) {
         std::vector<unsigned long long> bf(nbins);  // the tile kernels moved the counts here when they cleaned bin_fill
-        HIPCHK(d, hipMemcpyAsync(bf.data(), d->bin_count, nbins * 8, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(d, hipMemcpyAsync(bf.data(), sl.bin_count, nbins * 8, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
         for (size_t b = 0; b < nbins; b++) { entries[b] = (uint32_t)bf[b]; segments[b] = (uint32_t)(bf[b] >> 32); }
         return MTR_OK;
