@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # HBM bytes per launch of the two heaviest kernels on the headline scene, from rocprofv3 PMC passes run separately
 # (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B,
 # MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_b_pmc_*.csv).
-TRAFFIC_TILE_VIS = 49067929     # k_tile_vis<false>: 2 x 15505.3 KB fetched + 16907.3 KB written (framebuffer = 16.6 MB)
-TRAFFIC_GEOM_DIRECT = 49235046  # k_geom<true>:      2 x 7351.5 KB fetched + 33378.1 KB written (records + bin queues)
+TRAFFIC_TILE_VIS = 55059046     # k_tile_vis<false>: 2 x 18333.8 KB fetched + 17101.0 KB written (framebuffer = 16.6 MB)
+TRAFFIC_GEOM_DIRECT = 49288396  # k_geom<true>:      2 x 7377.1 KB fetched + 33379.0 KB written (records + bin queues)
 
 
 def algorithmic_bytes(md, width, height, npalettes, nbones=64):
