@@ -8,7 +8,7 @@
 A "step" is one frame: clear (fused) -> geometry -> bin -> tile raster/shade -> framebuffer complete in
 HBM (N > 1: after the RCCL all-gather of the colour shards).  All inputs (vertex/index buffers, bone
 palette, transforms) are resident in HBM before the timed region.  One process per GPU; N > 1 shards
-the 32x32-pixel bins over the ranks (bin % N == rank) and exchanges colour with one all-gather.
+the 16x16-pixel bins over the ranks (bin % N == rank) and exchanges colour with one all-gather.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HBM-bound accounting, hipEvent
 timing on the library's own stream) and `cpu_baseline` (the CPU oracle -- kind "port": the
@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with an unsharded render")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,10 +65,17 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # MTR_BENCH_BACKEND=gloo is a single-GPU rehearsal of the N > 1 path (all ranks share cuda:0, the gather is staged
+    # through host memory): it checks the plumbing, not the speed.  The driver's multi-GPU runs use nccl (= RCCL).
+    backend = os.environ.get("MTR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     from mt_renderer_amd import api, scene
 
@@ -78,7 +86,7 @@ def main():
     M = scene.to_f32_colmajor(scene.headline_transform(W, H))
 
     stream = torch.cuda.Stream()
-    dev = api.Device(local_rank, stream=stream.cuda_stream)
+    dev = api.Device(dev_index, stream=stream.cuda_stream)
     model = api.Model.new(dev, md)
     model.set_palette(palette)
 
@@ -102,7 +110,13 @@ def main():
         if world > 1:
             fr.pack_color_shard(shard.data_ptr(), shard.numel())
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered, shard)
+                if backend == "nccl":
+                    dist.all_gather_into_tensor(gathered, shard)
+                else:  # rehearsal: host-staged gather
+                    stream.synchronize()
+                    host = torch.empty(gathered.numel(), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(host, shard.cpu())
+                    gathered.copy_(host)
             dev.unpack_color_shards(gathered.data_ptr(), world, W, H, final.data_ptr())
         fr.close()
 
@@ -125,6 +139,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if args.verify and world > 1:
+        fr = api.Frame(dev, W, H)
+        model.render(fr, M)
+        fr.end()
+        ref = fr.color()
+        fr.close()
+        sync()
+        got = final.cpu().numpy().reshape(H, W, 4)
+        ok = bool((got == ref).all())
+        print(f"[rank {rank}] verify gathered frame == unsharded frame: {ok}", file=sys.stderr, flush=True)
+        if not ok:
+            sys.exit(3)
     ms_per_step = dt * 1e3 / args.steps
     mtris = ntris / (ms_per_step * 1e-3) / 1e6
 

@@ -7,7 +7,7 @@
 // primitive restart (0xFFFF, src/model.rs:251) and strip parity come from one wave ballot.
 // Survivors of trivial reject / near clip / back-face cull / empty-bbox are compacted with
 // ballot + popcount into ONE contiguous, submission-ordered run of records per wave, and the
-// (triangle -> 32x32 bin) counts are accumulated with one 64-bit atomic per (wave, bin) group.
+// (triangle -> 16x16 bin) counts are accumulated with one 64-bit atomic per (wave, bin) group.
 //
 // Replaces everything between `rpass.draw_indexed` (src/model.rs:357-361) and the rasteriser.
 #include "geom_common.h"
@@ -59,6 +59,20 @@ struct Rec {
     RecB b;
     RecHdr h;
 };
+
+// true if some bin b of the rectangle has b % world == rank (bins are dealt round-robin in row-major order)
+__device__ __forceinline__ bool owns_any_bin(const RecHdr& h, uint32_t nbx, uint32_t rank, uint32_t world) {
+    const uint32_t w = (uint32_t)h.bx1 - h.bx0;  // width - 1
+    if (w + 1 >= world) return true;              // `world` consecutive ids hit every residue
+    const uint32_t rows = (uint32_t)h.by1 - h.by0 + 1;
+    if (rows > 8) return true;                    // tall and narrow: rare, keep (the binner filters exactly)
+    for (uint32_t y = h.by0; y <= h.by1; y++) {
+        const uint32_t first = (y * nbx + h.bx0) % world;
+        const uint32_t d = rank >= first ? rank - first : rank + world - first;
+        if (d <= w) return true;
+    }
+    return false;
+}
 
 // back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill
 __device__ __forceinline__ bool setup_tri(const PV& a, const PV& b, const PV& c, uint32_t W, uint32_t H, uint32_t mat,
@@ -233,6 +247,15 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
                 n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
             }
         }
+    }
+
+    // ---- sharded frames: a rank keeps only the triangles whose bin rectangle holds one of its bins (bin % world ==
+    //      rank), so records, queue traffic and binning work shrink with the shard.  Relative order is preserved.
+    if (P.fb.shard_world > 1 && n_out) {
+        const bool k0 = owns_any_bin(r0.h, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world);
+        const bool k1 = n_out == 2 && owns_any_bin(r1.h, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world);
+        if (!k0 && k1) r0 = r1;
+        n_out = (k0 ? 1u : 0u) + (k1 ? 1u : 0u);
     }
 
     // ---- wave compaction: one contiguous, ordered run of records per chunk ----

@@ -1,0 +1,24 @@
+"""Two ranks on one GPU: the N > 1 path of bench.py end to end (set_shard -> render -> pack -> all-gather -> unpack),
+with the gathered frame compared bit for bit with an unsharded render.  The exchange goes through gloo and
+host memory here (MTR_BENCH_BACKEND=gloo): one card cannot host two RCCL ranks; the driver's 2/4/8-GPU runs use nccl."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_gathered_frame_matches_unsharded():
+    env = dict(os.environ, MTR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--verify"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("verify gathered frame == unsharded frame: True") == 2, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["sharding"] == "bins % 2"
