@@ -131,8 +131,8 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     uint32_t seg_lo, S, ent_lo, n_ent;
     bin_queue(P.fb, bin, ent_lo, n_ent, seg_lo, S);
     if (P.fb.direct && lane == 0 && n_ent) {  // queue statistics (direct mode has no scan to count them)
-        atomicAdd(&P.fb.counters[CTR_ENT_SHARDS + (bin & (CTR_NSHARDS - 1))], n_ent);
-        atomicAdd(&P.fb.counters[CTR_SEG_SHARDS + (bin & (CTR_NSHARDS - 1))], S);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], n_ent);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], S);
     }
     const Seg* segs = P.fb.segs + seg_lo;
 

@@ -169,8 +169,8 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
     bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
     if (P.fb.direct && threadIdx.x == 0 && N) {  // queue statistics (direct mode has no scan to count them)
-        atomicAdd(&P.fb.counters[CTR_ENT_SHARDS + (bin & (CTR_NSHARDS - 1))], N);
-        atomicAdd(&P.fb.counters[CTR_SEG_SHARDS + (bin & (CTR_NSHARDS - 1))], n_seg);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
     }
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the

@@ -924,14 +924,14 @@ int32_t mtr_frame_wait(mtr_frame* f) {
         HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
         f->stats.tris_setup = 0;
-        for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[CTR_REC_SHARDS + k];
+        for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[MTR_CTR(CTR_REC, k)];
         f->stats.bin_entries = ctr[CTR_ENTRIES];
         f->stats.segments = ctr[CTR_SEGS];
         if (f->ran_direct) {  // no scan in direct mode: the tile kernels counted the queues
             f->stats.bin_entries = f->stats.segments = 0;
             for (int k = 0; k < CTR_NSHARDS; k++) {
-                f->stats.bin_entries += ctr[CTR_ENT_SHARDS + k];
-                f->stats.segments += ctr[CTR_SEG_SHARDS + k];
+                f->stats.bin_entries += ctr[MTR_CTR(CTR_ENT, k)];
+                f->stats.segments += ctr[MTR_CTR(CTR_SEG, k)];
             }
         }
         f->stats.binning = f->ran_direct ? 1u : 2u;

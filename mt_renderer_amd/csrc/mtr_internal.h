@@ -76,11 +76,13 @@ struct Seg {             // 16 B
     uint32_t pad;
 };
 
-// counters[]: [1] entries, [2] segments, [3] overflow flags, [16..79] surviving-triangle count shards
-// [80..143] / [144..207]: (triangle, bin) pair and segment count shards, filled by the tile kernels in direct mode
+// counters[]: [1] entries, [2] segments (two-pass scan), [3] overflow flags, then CTR_NSHARDS statistics shards of one
+// 128-byte line each: {surviving triangles, (triangle, bin) pairs, segments}.  One line per shard: atomics that share
+// a line serialise in its L2 channel (64 shards packed into two lines cost k_geom 20 us on the headline scene).
 // CTR_OVERFLOW bits: 1 record capacity (impossible), 2 two-pass queue capacity, 4 direct-mode per-bin queue full
-enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_REC_SHARDS = 16, CTR_NSHARDS = 64, CTR_ENT_SHARDS = 80,
-       CTR_SEG_SHARDS = 144, CTR_NUM = 208 };
+enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_SHARD_BASE = 32, CTR_SHARD_STRIDE = 32, CTR_NSHARDS = 128,
+       CTR_REC = 0, CTR_ENT = 1, CTR_SEG = 2, CTR_NUM = CTR_SHARD_BASE + CTR_NSHARDS * CTR_SHARD_STRIDE };
+#define MTR_CTR(kind, k) (CTR_SHARD_BASE + ((k) & (CTR_NSHARDS - 1)) * CTR_SHARD_STRIDE + (kind))
 
 struct FrameBuffers {
     RecHdr* rec_hdr;

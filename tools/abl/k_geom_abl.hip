@@ -177,12 +177,20 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     PV me;
     me.X = 0; me.Y = 0; me.z = 0.0f; me.iw = 0.0f; me.up = 0.0f; me.vp = 0.0f; me.flags = 0;
     // skinning + MVP on the matrix cores, wave-wide (all 64 lanes issue the MFMAs; invalid lanes carry zeros)
+#ifdef ABL_NOSKIN
+    const VOut v = shade_vertex_mfma(P.vbuf, pr, vid, vvalid, M, s_pal, P.npal, false);
+#else
     const VOut v = shade_vertex_mfma(P.vbuf, pr, vid, vvalid, M, s_pal, P.npal, skinned);
+#endif
     if (vvalid) {
         me = project(v, W, H);
         me.flags |= 1u | (outcode(v) << 2);
     }
 
+#ifdef ABL_EARLY
+    if (me.X == 0x7fffffff) P.fb.chunk_info[gid].n = me.Y;
+    return;
+#endif
     // ---- strip assembly: which lanes complete a triangle, and its winding parity ----
     const uint64_t R = __ballot(is_restart);
     const uint64_t below = R & ((1ull << lane) - 1ull);
@@ -220,7 +228,9 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     if (tri) {
         if (!((f_or >> 2) & OC_ZN)) {
             if (setup_tri(ta, tb, tc, W, H, mat, r0)) n_out = 1;
-        } else {
+        }
+#ifndef ABL_NOCLIP
+        else {
             // near-plane clip (z >= 0): rare, re-shades the three vertices in clip space
             const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
             VOut cv[3] = {shade_vertex(P.vbuf, pr, ia, M, s_pal, P.npal, skinned),
@@ -247,6 +257,7 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
                 n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
             }
         }
+#endif
     }
 
     // ---- sharded frames: a rank keeps only the triangles whose bin rectangle holds one of its bins (bin % world ==
@@ -268,19 +279,27 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     if (lane == 0) {
         ChunkInfo ci = {base, total};
         P.fb.chunk_info[gid] = ci;
-        if (total) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], total);  // statistics only
+#ifndef ABL_NOSTAT
+        if (total) atomicAdd(&P.fb.counters[CTR_REC_SHARDS + (gid & (CTR_NSHARDS - 1))], total);  // statistics only
+#endif
     }
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
     // texcoord planes are only read by textured materials: do not spend 48 B/triangle of HBM writes otherwise
+#ifdef ABL_NOMAT
+    DMat dmat{}; dmat.rgba8 = mat; dmat.shader = MTR_SH_DEBUG;
+#else
     const DMat dmat = P.mats[mat];  // wave-uniform
+#endif
     const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
     // the fragment stage finds the source colour / shader class in the record itself: no dependent material lookup
     r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8);
     r1.a.pad0 = dmat.rgba8; r1.a.pad1 = dmat.shader | (dmat.blend << 8);
     if (n_out >= 1) {
+#ifndef ABL_NOREC
         P.fb.rec_a[base + rank] = r0.a;
         P.fb.rec_hdr[base + rank] = r0.h;
+#endif
         if (want_b) P.fb.rec_b[base + rank] = r0.b;
         s_hdr[wave][rank] = r0.h;
     }
@@ -297,6 +316,10 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
 
     // ---- triangle -> bin: DIRECT = single-pass binning straight into the bounded per-bin queues;
     //      otherwise count only (one non-returning atomic per (wave, bin) group), k_scan + k_fill follow ----
+#ifdef ABL_NOBIN
+    if (s_hdr[wave][lane].bx0 == 0x7fff) P.fb.chunk_info[gid].n = 1;
+    return;
+#endif
     for (uint32_t round = 0; round * 64 < total; ++round) {
         const uint32_t j = round * 64 + lane;
         const bool act = j < total;
@@ -334,7 +357,10 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     uint32_t nblk = (p.nchunks + 3) / 4;
     nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
     dim3 grid(nblk, p.ninst);
-    size_t lds = (size_t)p.npal * 64;
+#ifndef ABL_LDS
+#define ABL_LDS 0
+#endif
+    size_t lds = (size_t)p.npal * 64 + ABL_LDS;
     if (p.fb.direct) hipLaunchKernelGGL(mtr::k_geom<true>, grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL(mtr::k_geom<false>, grid, dim3(256), lds, s, p);
 }
