@@ -194,6 +194,19 @@ __device__ __forceinline__ bool bin_owned(uint32_t bin, uint32_t rank, uint32_t 
     return world <= 1 || (bin % world) == rank;
 }
 
+// wave-wide minimum as a scalar: rotate-and-min inside each row of 16 lanes with DPP (row_ror 8/4/2/1; min is
+// idempotent, so rotations give every lane its row's minimum), then four v_readlane + scalar min across the rows.
+// Six ds_bpermute shuffles did this before and were the long pole of the binning loop (~700 cycles per group).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 template <class F>
 __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t nbx, uint32_t rank, uint32_t world, F f) {
     uint32_t bx = h.bx0, by = h.by0;
@@ -209,9 +222,7 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
         // (= submission) order: one ordered segment per (chunk, round, bin)
         uint32_t mybin = by * nbx + bx;
         uint32_t b = act ? mybin : 0xFFFFFFFFu;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) b = min(b, (uint32_t)__shfl_xor((int)b, d));
-        b = __builtin_amdgcn_readfirstlane(b);
+        b = wave_min_u32(b);
         bool hit = act && mybin == b;
         uint64_t m = __ballot(hit);
         f(b, m, hit);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         ChunkInfo ci = {base, total};
         P.fb.chunk_info[gid] = ci;
 #ifndef ABL_NOSTAT
-        if (total) atomicAdd(&P.fb.counters[CTR_REC_SHARDS + (gid & (CTR_NSHARDS - 1))], total);  // statistics only
+        if (total) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], total);  // statistics only
 #endif
     }
     total = __builtin_amdgcn_readfirstlane(total);
