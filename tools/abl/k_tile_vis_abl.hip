@@ -134,31 +134,20 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
 }
 
 // waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
-// the keys are order-independent, so the waves only meet at the two barriers around the raster loop.  This
-// cuts the serial chain of the heaviest bins (the long pole of the kernel) by VIS_WAVES.
-#ifndef VIS_LANE_MAX
-#define VIS_LANE_MAX 32  // bbox-in-bin pixels a lane walks by itself before the triangle goes to the flattened phase
-#endif
-#ifndef VIS_OCC
-#define VIS_OCC 8  // waves per SIMD the register allocator must leave room for (the kernel is latency-bound per bin)
-#endif
-#define VIS_P2 16  // triangles per flattened (phase 2) sub-batch: keeps the per-wave LDS at 1.3 KB -> 32 waves per CU
+// the keys are order-independent, so the waves only meet at the two barriers around the raster loop.
 #ifndef VIS_WAVES
 #define VIS_WAVES 2  // measured on the headline scene (tools/sweep_vis_waves.sh): 1: 104 us, 2: 73 us, 4: 83 us, 8: 129 us
+#endif
+#ifndef VIS_OCC
+#define VIS_OCC 6    // waves per SIMD the register allocator must leave room for (no spills at 6)
 #endif
 
 template <bool TEX>
 __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams P) {
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
-    __shared__ __align__(16) VisTri s_tri_all[VIS_WAVES][VIS_P2];
-    __shared__ __align__(16) int4 s_chi_all[VIS_WAVES][VIS_P2];
-    __shared__ uint32_t s_pre_all[VIS_WAVES][VIS_P2 + 1];
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    VisTri* s_tri = s_tri_all[wv];
-    int4* s_chi = s_chi_all[wv];
-    uint32_t* s_pre = s_pre_all[wv];
     uint32_t bin;
     if (!block_to_bin(P.fb, bin)) return;  // uniform over the workgroup, before any barrier
     const uint32_t nbx = P.fb.nbx;
@@ -180,8 +169,8 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
     bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
     if (P.fb.direct && threadIdx.x == 0 && N) {  // queue statistics (direct mode has no scan to count them)
-        atomicAdd(&P.fb.counters[CTR_ENT_SHARDS + (bin & (CTR_NSHARDS - 1))], N);
-        atomicAdd(&P.fb.counters[CTR_SEG_SHARDS + (bin & (CTR_NSHARDS - 1))], n_seg);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
+        atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
     }
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
@@ -197,11 +186,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     }
     RecA a_cur = zero_rec;
     if (first + lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
-#ifdef ABL_NO_RASTER
-    for (uint32_t e0 = first; e0 < 0; e0 += stride) {
-#else
     for (uint32_t e0 = first; e0 < N; e0 += stride) {
-#endif
         const bool valid = e0 + lane < N;
         RecA a_nxt = zero_rec;
         if (e0 + stride + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
@@ -209,17 +194,34 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
         Setup s = {};
+#ifdef ABL_T_NOSETUP
+        if (valid && a_cur.X0 == 0x7ffffff0) s_key[0] = 1;
+#else
         if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, s);
-
-        // ---- phase 1, lane = triangle: a triangle whose bbox holds at most VIS_LANE_MAX pixels of this bin is
-        //      walked by its own lane with incremental edge functions (3 adds per pixel, no LDS lookups); the
-        //      micro-triangle regime of the headline scene lives here ----
-#ifdef ABL_NO_PHASES
-        if (s.npx == 12345) s_key[lane] = s.t.ordk;
-        a_cur = a_nxt; ord_cur = ord_nxt; ord_nxt = ord_nn;
-        continue;
 #endif
-        const bool small = s.npx > 0 && s.npx <= VIS_LANE_MAX && !(s.t.flags & 1u);
+        const bool large = (s.t.flags & 1u) != 0;
+        const uint32_t npx = (uint32_t)s.npx;
+
+        // ---- how to split this pass: a lane walks its own triangle when its bbox holds <= thr pixels of the bin
+        //      (cost ~ thr iterations for the whole wave); bigger and 64-bit triangles are rasterised by the whole
+        //      wave, one at a time (cost ~ constant + bbox/64 iterations each).  Pick thr per pass. ----
+        uint32_t thr = 16, best = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t c = 16; c <= 256; c <<= 1) {
+            const uint32_t nbig = (uint32_t)__popcll(__ballot(npx != 0 && (large || npx > c)));
+            const uint32_t nsmall = (uint32_t)__popcll(__ballot(npx != 0 && !large && npx <= c));
+            const uint32_t cost = (nsmall ? c * 18u : 0u) + nbig * 110u;
+            if (cost < best) { best = cost; thr = c; }
+        }
+#ifdef ABL_T_NOCOST
+        thr = 64;
+#endif
+        const bool small = npx != 0 && !large && npx <= thr;
+#ifdef ABL_T_NORASTER
+        if (s.t.A0 + s.t.C1 + s.t.B2 == 0x7ffffff0 && small) s_key[1] = 1;
+#else
+
+        // ---- lane = triangle, incremental edge functions: 3 adds per pixel, no LDS lookups ----
         {
             const uint32_t box = s.t.box;
             const int32_t px0 = (int32_t)(box & 15u), py0 = (int32_t)((box >> 4) & 15u), px1 = px0 + (int32_t)((box >> 8) & 15u);
@@ -228,8 +230,12 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             int32_t r1 = s.t.C1 + __mul24(s.t.A1, px0) + __mul24(s.t.B1, py0);
             int32_t r2 = s.t.C2 + __mul24(s.t.A2, px0) + __mul24(s.t.B2, py0);
             int32_t eb0 = r0, eb1 = r1, eb2 = r2;
-            for (int32_t k = 0;; k++) {
-                const bool act = small && k < s.npx;
+            for (uint32_t k = 0;; k++) {
+#ifdef ABL_T_NOSMALL
+                const bool act = false;
+#else
+                const bool act = small && k < npx;
+#endif
                 if (!__ballot(act)) break;
                 if (act) {
                     if ((eb0 | eb1 | eb2) >= 0) {
@@ -237,7 +243,11 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                         const float b2 = (float)(eb2 + (int32_t)((s.t.flags >> 6) & 1u)) * s.t.rcpA;
                         const float z = fmaf(b2, s.t.dz2, fmaf(b1, s.t.dz1, s.t.z0));
                         if (z >= 0.0f && z <= 1.0f && z <= cd && cx < vw && cy < vh)
+#ifdef ABL_T_NOATOM
+                            s_key[cy * MTR_BIN + cx] = make_key(z, s.t.ordk);
+#else
                             atomicMax(&s_key[cy * MTR_BIN + cx], make_key(z, s.t.ordk));
+#endif
                     }
                     eb0 += s.t.A0; eb1 += s.t.A1; eb2 += s.t.A2;
                     if (++cx > px1) {
@@ -249,89 +259,53 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             }
         }
 
-        // ---- phase 2: everything else (big or 64-bit triangles), flattened over the wave ----
-        const uint32_t npx2 = small ? 0u : (uint32_t)s.npx;
-        if (__ballot(npx2 != 0) == 0) {  // wave-uniform: nothing left in this pass
-            a_cur = a_nxt;
-            ord_cur = ord_nxt;
-            ord_nxt = ord_nn;
-            continue;
-        }
-#ifdef ABL_NO_P2
-        for (uint64_t mb = 0; mb;) {
+        // ---- lane = pixel of the bbox: the remaining triangles, broadcast one at a time with v_readlane ----
+#ifdef ABL_T_NOCOOP
+        for (uint64_t mb = 0; mb; mb &= mb - 1) {
 #else
-        for (uint64_t mb = __ballot(npx2 != 0); mb;) {
+        for (uint64_t mb = __ballot(npx != 0 && !small); mb; mb &= mb - 1) {
 #endif
-        // the next (up to) VIS_P2 pending triangles, compacted into LDS
-        const uint32_t myrank = (uint32_t)__popcll(mb & ((1ull << lane) - 1ull));
-        const bool sel = ((mb >> lane) & 1ull) && myrank < VIS_P2;
-        const uint64_t selm = __ballot(sel);
-        mb &= ~selm;
-        // exclusive prefix of the selected triangles' pixel counts
-        const uint32_t mine = sel ? npx2 : 0u;
-        uint32_t inc = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, d);
-            if ((int)lane >= d) inc += t;
-        }
-        const uint32_t T = (uint32_t)__shfl((int)inc, 63);
-        const uint32_t nsel = (uint32_t)__popcll(selm);
-        if (sel) {
-            s_tri[myrank] = s.t;
-            s_chi[myrank] = s.chi;
-            s_pre[myrank] = inc - mine;
-        }
-        if (lane >= nsel && lane <= VIS_P2) s_pre[lane] = T;  // unused slots never win the search (w < T)
-        wave_lds_sync();
-
-        // ---- flattened (triangle, pixel) work items: item w belongs to triangle j with pre[j] <= w < pre[j+1] ----
-        for (uint32_t w0 = 0; w0 < T; w0 += 64) {
-            const uint32_t w = w0 + lane;
-            if (w < T) {
-                uint32_t lo = 0, hi = VIS_P2;  // largest j with s_pre[j] <= w
-#pragma unroll
-                for (int it = 0; it < 4; it++) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s_pre[mid] <= w) lo = mid; else hi = mid;
-                }
-                const int4* tp = reinterpret_cast<const int4*>(&s_tri[lo]);
-                const int4 q0 = tp[0], q1 = tp[1], q2 = tp[2], q3 = tp[3];
-                const uint32_t flags = (uint32_t)q2.y, box = (uint32_t)q3.w;
-                const uint32_t k = w - s_pre[lo];
-                const uint32_t row = (k * (box >> 12)) >> 16, bw = ((box >> 8) & 15u) + 1u;
+            const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)mb) - 1);
+#define RL(x) __builtin_amdgcn_readlane((int)(x), t)
+            const int32_t A0 = RL(s.t.A0), B0 = RL(s.t.B0), C0 = RL(s.t.C0), A1 = RL(s.t.A1), B1 = RL(s.t.B1), C1 = RL(s.t.C1);
+            const int32_t A2 = RL(s.t.A2), B2 = RL(s.t.B2), C2 = RL(s.t.C2);
+            const uint32_t flags = (uint32_t)RL(s.t.flags), box = (uint32_t)RL(s.t.box), tord = (uint32_t)RL(s.t.ordk), tn = (uint32_t)RL(npx);
+            const float z0 = __int_as_float(RL(__float_as_int(s.t.z0))), dz1 = __int_as_float(RL(__float_as_int(s.t.dz1)));
+            const float dz2 = __int_as_float(RL(__float_as_int(s.t.dz2))), rcpA = __int_as_float(RL(__float_as_int(s.t.rcpA)));
+            const int32_t H0 = RL(s.chi.x), H1 = RL(s.chi.y), H2 = RL(s.chi.z);
+#undef RL
+            const uint32_t bw = ((box >> 8) & 15u) + 1u, magic = box >> 12;
+            for (uint32_t k = lane; k < tn; k += 64) {
+                const uint32_t row = (k * magic) >> 16;
                 const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
                 bool inside;
                 float e1f, e2f;
                 if (!(flags & 1u)) {
-                    const int32_t eb0 = q0.z + __mul24(q0.x, lx) + __mul24(q0.y, ly);
-                    const int32_t eb1 = q1.y + __mul24(q0.w, lx) + __mul24(q1.x, ly);
-                    const int32_t eb2 = q2.x + __mul24(q1.z, lx) + __mul24(q1.w, ly);
+                    const int32_t eb0 = C0 + __mul24(A0, lx) + __mul24(B0, ly);
+                    const int32_t eb1 = C1 + __mul24(A1, lx) + __mul24(B1, ly);
+                    const int32_t eb2 = C2 + __mul24(A2, lx) + __mul24(B2, ly);
                     inside = (eb0 | eb1 | eb2) >= 0;
                     e1f = (float)(eb1 + (int32_t)((flags >> 5) & 1u));
                     e2f = (float)(eb2 + (int32_t)((flags >> 6) & 1u));
                 } else {
-                    const int4 ch = s_chi[lo];
                     const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
-                    const long long c0 = ((long long)ch.x << 32) | (unsigned long long)(uint32_t)q0.z;
-                    const long long c1 = ((long long)ch.y << 32) | (unsigned long long)(uint32_t)q1.y;
-                    const long long c2 = ((long long)ch.z << 32) | (unsigned long long)(uint32_t)q2.x;
-                    const long long eb0 = c0 + (long long)q0.x * Xp + (long long)q0.y * Yp;
-                    const long long eb1 = c1 + (long long)q0.w * Xp + (long long)q1.x * Yp;
-                    const long long eb2 = c2 + (long long)q1.z * Xp + (long long)q1.w * Yp;
+                    const long long c0 = ((long long)H0 << 32) | (unsigned long long)(uint32_t)C0;
+                    const long long c1 = ((long long)H1 << 32) | (unsigned long long)(uint32_t)C1;
+                    const long long c2 = ((long long)H2 << 32) | (unsigned long long)(uint32_t)C2;
+                    const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
+                    const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
+                    const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
                     inside = (eb0 | eb1 | eb2) >= 0;
                     e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
                     e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
                 }
-                const float rcpA = __int_as_float(q3.y);
                 const float b1 = e1f * rcpA, b2 = e2f * rcpA;
-                const float z = fmaf(b2, __int_as_float(q3.x), fmaf(b1, __int_as_float(q2.w), __int_as_float(q2.z)));
-                const bool pass = inside && z >= 0.0f && z <= 1.0f && z <= cd && lx < vw && ly < vh;
-                if (pass) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, (uint32_t)q3.z));
+                const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
+                if (inside && z >= 0.0f && z <= 1.0f && z <= cd && lx < vw && ly < vh)
+                    atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
             }
         }
-        wave_lds_sync();  // the next sub-batch overwrites s_tri / s_pre
-        }
+#endif
         a_cur = a_nxt;
         ord_cur = ord_nxt;
         ord_nxt = ord_nn;
@@ -348,16 +322,16 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         const unsigned long long key = s_key[ly * MTR_BIN + lx];
         uint32_t col = P.clear_rgba8;
         float dep = cd;
-#ifdef ABL_NO_RESOLVE
-        if (false) {
-#else
         if (key != 0ull) {
-#endif
             dep = __uint_as_float(~(uint32_t)(key >> 32));
             const uint32_t ord = (uint32_t)key - 1u;
             const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
             // third 16-byte word of the record: {z2, material id, material rgba8, shader | blend << 8}
+#ifdef ABL_T_NOWINNER
+            const uint4 tail = {r, r, r, 0u};
+#else
             const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];
+#endif
             if (TEX && (tail.w & 0xffu) == MTR_SH_TEXTURED) {
                 const RecA a = P.fb.rec_a[r];
                 const RecB b = P.fb.rec_b[r];
