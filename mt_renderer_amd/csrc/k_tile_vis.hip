@@ -214,33 +214,9 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);
         const bool large = (s.t.flags & 1u) != 0;
         const uint32_t npx = (uint32_t)s.npx;
-        // flat class: i32 edge functions and at most 64 pixels of the bin's 256, so a pass holds <= 4096 pairs
-        const bool flat = npx != 0 && !large && npx <= 64u;
-        const uint64_t fm = __ballot(flat);
-        uint32_t total = 0;
-        if (fm) {
-            // ---- stage the flat triangles, compacted, with their pair prefix; mark where each one starts ----
-            const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-            const uint32_t mine = flat ? npx : 0u;
-            const uint32_t inc = wave_incl_scan_u32(mine);
-            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            const uint32_t pre = inc - mine;
-            s_start[wv][lane] = 0ull;
-            wave_lds_sync();
-            if (flat) {
-                uint4* dst = &s_flat[wv][cidx * 4];
-                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)s.t.C0, (uint32_t)s.t.A1);
-                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)s.t.C1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
-                dst[2] = make_uint4((uint32_t)s.t.C2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
-                // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
-                dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
-                atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
-            }
-            wave_lds_sync();
-        }
-
-        // ---- lane = pixel of the bbox: the big triangles, broadcast one at a time with v_readlane ----
-        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {
+        // ---- lane = pixel of the bbox: triangles that need 64-bit edge functions (more than 64 px across: rare),
+        //      broadcast one at a time with v_readlane ----
+        for (uint64_t mb = __ballot(npx != 0 && large); mb; mb &= mb - 1) {
             const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)mb) - 1);
 #define RL(x) __builtin_amdgcn_readlane((int)(x), t)
             const int32_t A0 = RL(s.t.A0), B0 = RL(s.t.B0), C0 = RL(s.t.C0), A1 = RL(s.t.A1), B1 = RL(s.t.B1), C1 = RL(s.t.C1);
@@ -254,35 +230,47 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             for (uint32_t k = lane; k < tn; k += 64) {
                 const uint32_t row = (k * magic) >> 16;
                 const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
-                bool inside;
-                float e1f, e2f;
-                if (!(flags & 1u)) {
-                    const int32_t eb0 = C0 + __mul24(A0, lx) + __mul24(B0, ly);
-                    const int32_t eb1 = C1 + __mul24(A1, lx) + __mul24(B1, ly);
-                    const int32_t eb2 = C2 + __mul24(A2, lx) + __mul24(B2, ly);
-                    inside = (eb0 | eb1 | eb2) >= 0;
-                    e1f = (float)(eb1 + (int32_t)((flags >> 5) & 1u));
-                    e2f = (float)(eb2 + (int32_t)((flags >> 6) & 1u));
-                } else {
-                    const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
-                    const long long c0 = ((long long)H0 << 32) | (unsigned long long)(uint32_t)C0;
-                    const long long c1 = ((long long)H1 << 32) | (unsigned long long)(uint32_t)C1;
-                    const long long c2 = ((long long)H2 << 32) | (unsigned long long)(uint32_t)C2;
-                    const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
-                    const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
-                    const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
-                    inside = (eb0 | eb1 | eb2) >= 0;
-                    e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
-                    e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
-                }
+                const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
+                const long long c0 = ((long long)H0 << 32) | (unsigned long long)(uint32_t)C0;
+                const long long c1 = ((long long)H1 << 32) | (unsigned long long)(uint32_t)C1;
+                const long long c2 = ((long long)H2 << 32) | (unsigned long long)(uint32_t)C2;
+                const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
+                const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
+                const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
+                const bool inside = (eb0 | eb1 | eb2) >= 0;
+                const float e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
+                const float e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
                 const float b1 = e1f * rcpA, b2 = e2f * rcpA;
                 const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
                 if (inside && z >= 0.0f && z <= 1.0f && z <= cd) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
             }
         }
 
-        // ---- lane = (triangle, pixel) pair of the flat class, 64 pairs per step ----
-        if (total) {
+        // ---- lane = (triangle, pixel) pair, 64 pairs per step, for every i32-class triangle.  A round stages a
+        //      prefix of the remaining triangles holding <= 4096 pairs (64 start masks, one per lane); one round
+        //      is the rule, a pass of 64 bin-filling triangles takes four. ----
+        for (uint64_t todo = __ballot(npx != 0 && !large); todo;) {
+            const bool cand = (todo >> lane) & 1ull;
+            const uint32_t mine = cand ? npx : 0u;
+            const uint32_t inc = wave_incl_scan_u32(mine);
+            const bool take = cand && inc <= 4096u;  // npx <= 256: the first candidate always fits
+            const uint64_t tm = __ballot(take);
+            todo &= ~tm;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63 - __builtin_clzll(tm));
+            const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+            const uint32_t pre = inc - mine;
+            s_start[wv][lane] = 0ull;
+            wave_lds_sync();
+            if (take) {
+                uint4* dst = &s_flat[wv][cidx * 4];
+                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)s.t.C0, (uint32_t)s.t.A1);
+                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)s.t.C1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
+                dst[2] = make_uint4((uint32_t)s.t.C2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
+                // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
+                dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
+                atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
+            }
+            wave_lds_sync();
             const unsigned long long my_start = s_start[wv][lane];
             const uint32_t nb = (total + 63u) >> 6;
             uint32_t base = 0;

@@ -5,11 +5,13 @@
 // a = 1) is a pure reduction: the winner of a pixel is the fragment with the smallest z, the LATEST
 // in submission order among equals.  So each pixel keeps one 64-bit key  (~bits(z) : order+1)  in
 // LDS and every fragment is an order-independent, fire-and-forget `ds_max_u64`:
-//   * 64 triangles are set up per pass, one per lane, into LDS;
-//   * their (triangle, pixel-of-bbox) pairs are FLATTENED over the wave with a prefix sum (wave
-//     shuffles) + binary search, so a pass costs sum(bbox pixels)/64 iterations whatever the mix of
-//     1-pixel slivers and bin-filling triangles -- instead of a whole wave per (triangle, sub-tile)
-//     as in the ordered kernel;
+//   * 64 triangles are set up per pass, one per lane;
+//   * the (triangle, pixel-of-bbox) pairs of the triangles with <= 64 bbox pixels in the bin are FLATTENED over
+//     the wave: a pass costs sum(bbox pixels)/64 iterations whatever the mix of 1-pixel slivers and 8x8 patches
+//     (a lane = triangle walk ran max(bbox pixels) iterations at 29 % lane efficiency on the headline scene).
+//     The pair -> triangle map needs no search: triangle t sets bit (prefix_t mod 64) of a 64-bit start mask per
+//     batch of 64 pairs (one ds_or_b64), and pair p's triangle is  #starts before its batch + popcount(mask bits
+//     <= p) - 1  (v_mbcnt).  Bigger triangles are rasterised by the whole wave, one at a time (v_readlane);
 //   * shading is deferred: the winner's record is addressable from its order (chunk runs live at
 //     chunk * MTR_CHUNK_SLOTS), so the resolve does one colour lookup -- or one texture sample with the
 //     quad derivatives evaluated from the winner's plane equations exactly as SPEC.md section 7
@@ -41,7 +43,7 @@ struct Setup {
     int32_t npx;
 };
 
-__device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t binx0, int32_t biny0, Setup& s) {
+__device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t binx0, int32_t biny0, int32_t vw, int32_t vh, Setup& s) {
     const int32_t xmin = min(a.X0, min(a.X1, a.X2)), xmax = max(a.X0, max(a.X1, a.X2));
     const int32_t ymin = min(a.Y0, min(a.Y1, a.Y2)), ymax = max(a.Y0, max(a.Y1, a.Y2));
     const bool large = (xmax - xmin) > 16384 || (ymax - ymin) > 16384;
@@ -77,8 +79,8 @@ __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t b
         }
         fA2 = (float)((long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]));
     }
-    const int32_t px0 = max(((xmin + 127) >> 8) - binx0, 0), px1 = min(((xmax - 128) >> 8) - binx0, MTR_BIN - 1);
-    const int32_t py0 = max(((ymin + 127) >> 8) - biny0, 0), py1 = min(((ymax - 128) >> 8) - biny0, MTR_BIN - 1);
+    const int32_t px0 = max(((xmin + 127) >> 8) - binx0, 0), px1 = min(((xmax - 128) >> 8) - binx0, min(MTR_BIN, vw) - 1);
+    const int32_t py0 = max(((ymin + 127) >> 8) - biny0, 0), py1 = min(((ymax - 128) >> 8) - biny0, min(MTR_BIN, vh) - 1);
     const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
     s.npx = (bw > 0 && bh > 0) ? bw * bh : 0;
     const uint32_t ubw = (uint32_t)max(bw, 1);
@@ -92,6 +94,19 @@ __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t b
     s.t.ordk = ord + 1u;
     s.t.box = (uint32_t)(px0 & 15) | ((uint32_t)(py0 & 15) << 4) | ((uint32_t)((bw - 1) & 15) << 8) | (magic << 12);
     s.chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
+}
+
+// wave-wide inclusive prefix sum: Hillis-Steele inside each row of 16 lanes with DPP row_shr (lanes shifted in from
+// outside the row read 0), then the totals of the rows below are added (three v_readlane).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    return v + (row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2);
 }
 
 __device__ __forceinline__ unsigned long long make_key(float z, uint32_t ordk) {
@@ -145,6 +160,8 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
 template <bool TEX>
 __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams P) {
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
+    __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
+    __shared__ unsigned long long s_start[VIS_WAVES][64];     // per batch of 64 pairs: which pairs start a triangle
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -197,73 +214,44 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 #ifdef ABL_T_NOSETUP
         if (valid && a_cur.X0 == 0x7ffffff0) s_key[0] = 1;
 #else
-        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, s);
+        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);
 #endif
         const bool large = (s.t.flags & 1u) != 0;
         const uint32_t npx = (uint32_t)s.npx;
-
-        // ---- how to split this pass: a lane walks its own triangle when its bbox holds <= thr pixels of the bin
-        //      (cost ~ thr iterations for the whole wave); bigger and 64-bit triangles are rasterised by the whole
-        //      wave, one at a time (cost ~ constant + bbox/64 iterations each).  Pick thr per pass. ----
-        uint32_t thr = 16, best = 0xFFFFFFFFu;
-#pragma unroll
-        for (uint32_t c = 16; c <= 256; c <<= 1) {
-            const uint32_t nbig = (uint32_t)__popcll(__ballot(npx != 0 && (large || npx > c)));
-            const uint32_t nsmall = (uint32_t)__popcll(__ballot(npx != 0 && !large && npx <= c));
-            const uint32_t cost = (nsmall ? c * 18u : 0u) + nbig * 110u;
-            if (cost < best) { best = cost; thr = c; }
-        }
-#ifdef ABL_T_NOCOST
-        thr = 64;
-#endif
-        const bool small = npx != 0 && !large && npx <= thr;
-#ifdef ABL_T_NORASTER
-        if (s.t.A0 + s.t.C1 + s.t.B2 == 0x7ffffff0 && small) s_key[1] = 1;
+        // flat class: i32 edge functions and at most 64 pixels of the bin's 256, so a pass holds <= 4096 pairs
+        const bool flat = npx != 0 && !large && npx <= 64u;
+        const uint64_t fm = __ballot(flat);
+        uint32_t total = 0;
+#ifdef ABL_T_NOSTAGE
+        if (fm == 0x7ffffff0) {
 #else
-
-        // ---- lane = triangle, incremental edge functions: 3 adds per pixel, no LDS lookups ----
-        {
-            const uint32_t box = s.t.box;
-            const int32_t px0 = (int32_t)(box & 15u), py0 = (int32_t)((box >> 4) & 15u), px1 = px0 + (int32_t)((box >> 8) & 15u);
-            int32_t cx = px0, cy = py0;
-            int32_t r0 = s.t.C0 + __mul24(s.t.A0, px0) + __mul24(s.t.B0, py0);
-            int32_t r1 = s.t.C1 + __mul24(s.t.A1, px0) + __mul24(s.t.B1, py0);
-            int32_t r2 = s.t.C2 + __mul24(s.t.A2, px0) + __mul24(s.t.B2, py0);
-            int32_t eb0 = r0, eb1 = r1, eb2 = r2;
-            for (uint32_t k = 0;; k++) {
-#ifdef ABL_T_NOSMALL
-                const bool act = false;
-#else
-                const bool act = small && k < npx;
+        if (fm) {
 #endif
-                if (!__ballot(act)) break;
-                if (act) {
-                    if ((eb0 | eb1 | eb2) >= 0) {
-                        const float b1 = (float)(eb1 + (int32_t)((s.t.flags >> 5) & 1u)) * s.t.rcpA;
-                        const float b2 = (float)(eb2 + (int32_t)((s.t.flags >> 6) & 1u)) * s.t.rcpA;
-                        const float z = fmaf(b2, s.t.dz2, fmaf(b1, s.t.dz1, s.t.z0));
-                        if (z >= 0.0f && z <= 1.0f && z <= cd && cx < vw && cy < vh)
-#ifdef ABL_T_NOATOM
-                            s_key[cy * MTR_BIN + cx] = make_key(z, s.t.ordk);
-#else
-                            atomicMax(&s_key[cy * MTR_BIN + cx], make_key(z, s.t.ordk));
-#endif
-                    }
-                    eb0 += s.t.A0; eb1 += s.t.A1; eb2 += s.t.A2;
-                    if (++cx > px1) {
-                        cx = px0; cy++;
-                        r0 += s.t.B0; r1 += s.t.B1; r2 += s.t.B2;
-                        eb0 = r0; eb1 = r1; eb2 = r2;
-                    }
-                }
+            // ---- stage the flat triangles, compacted, with their pair prefix; mark where each one starts ----
+            const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            const uint32_t mine = flat ? npx : 0u;
+            const uint32_t inc = wave_incl_scan_u32(mine);
+            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            const uint32_t pre = inc - mine;
+            s_start[wv][lane] = 0ull;
+            wave_lds_sync();
+            if (flat) {
+                uint4* dst = &s_flat[wv][cidx * 4];
+                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)s.t.C0, (uint32_t)s.t.A1);
+                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)s.t.C1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
+                dst[2] = make_uint4((uint32_t)s.t.C2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
+                // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
+                dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
+                atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
             }
+            wave_lds_sync();
         }
 
-        // ---- lane = pixel of the bbox: the remaining triangles, broadcast one at a time with v_readlane ----
+        // ---- lane = pixel of the bbox: the big triangles, broadcast one at a time with v_readlane ----
 #ifdef ABL_T_NOCOOP
-        for (uint64_t mb = 0; mb; mb &= mb - 1) {
+        for (uint64_t mb = __ballot(npx == 0x7ffffff0); mb; mb &= mb - 1) {
 #else
-        for (uint64_t mb = __ballot(npx != 0 && !small); mb; mb &= mb - 1) {
+        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {
 #endif
             const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)mb) - 1);
 #define RL(x) __builtin_amdgcn_readlane((int)(x), t)
@@ -301,11 +289,45 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                 }
                 const float b1 = e1f * rcpA, b2 = e2f * rcpA;
                 const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
-                if (inside && z >= 0.0f && z <= 1.0f && z <= cd && lx < vw && ly < vh)
-                    atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
+                if (inside && z >= 0.0f && z <= 1.0f && z <= cd) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
             }
         }
+
+        // ---- lane = (triangle, pixel) pair of the flat class, 64 pairs per step ----
+#ifdef ABL_T_NOFLAT
+        if (total == 0x7ffffff0) {
+#else
+        if (total) {
 #endif
+            const unsigned long long my_start = s_start[wv][lane];
+            const uint32_t nb = (total + 63u) >> 6;
+            uint32_t base = 0;
+            for (uint32_t b = 0; b < nb; b++) {
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_start, b);
+                const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_start >> 32), b);
+                const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+                // triangles started before this batch + starts at or below this lane - 1
+                const uint32_t tri = base + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (uint32_t)((m >> lane) & 1ull) - 1u;
+                base += (uint32_t)__popcll(m);
+                const uint32_t p = b * 64u + lane;
+                if (p < total) {
+                    const uint4* src = &s_flat[wv][tri * 4];
+                    const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                    const uint32_t box = q3.w, k = p - q2.y;
+                    const uint32_t bw = ((box >> 8) & 15u) + 1u, magic = (box >> 12) & 0x1ffffu;
+                    const uint32_t row = (k * magic) >> 16;
+                    const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
+                    const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, lx) + __mul24((int32_t)q0.y, ly);
+                    const int32_t eb1 = (int32_t)q1.y + __mul24((int32_t)q0.w, lx) + __mul24((int32_t)q1.x, ly);
+                    const int32_t eb2 = (int32_t)q2.x + __mul24((int32_t)q1.z, lx) + __mul24((int32_t)q1.w, ly);
+                    const float b1 = (float)(eb1 + (int32_t)((box >> 29) & 1u)) * __uint_as_float(q3.y);
+                    const float b2 = (float)(eb2 + (int32_t)((box >> 30) & 1u)) * __uint_as_float(q3.y);
+                    const float z = fmaf(b2, __uint_as_float(q3.x), fmaf(b1, __uint_as_float(q2.w), __uint_as_float(q2.z)));
+                    if ((eb0 | eb1 | eb2) >= 0 && z >= 0.0f && z <= 1.0f && z <= cd)
+                        atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, q3.z));
+                }
+            }
+        }
         a_cur = a_nxt;
         ord_cur = ord_nxt;
         ord_nxt = ord_nn;

@@ -11,17 +11,16 @@ def sub(old, new):
     s = s.replace(old, new)
 
 
-sub("        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, s);",
+sub("        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);",
     "#ifdef ABL_T_NOSETUP\n        if (valid && a_cur.X0 == 0x7ffffff0) s_key[0] = 1;\n#else\n"
-    "        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, s);\n#endif")
-sub("        const bool small = npx != 0 && !large && npx <= thr;\n",
-    "#ifdef ABL_T_NOCOST\n        thr = 64;\n#endif\n        const bool small = npx != 0 && !large && npx <= thr;\n"
-    "#ifdef ABL_T_NORASTER\n        if (s.t.A0 + s.t.C1 + s.t.B2 == 0x7ffffff0 && small) s_key[1] = 1;\n#else\n")
-sub("        a_cur = a_nxt;\n        ord_cur = ord_nxt;", "#endif\n        a_cur = a_nxt;\n        ord_cur = ord_nxt;")
+    "        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);\n#endif")
+sub("        if (total) {\n            const unsigned long long my_start",
+    "#ifdef ABL_T_NOFLAT\n        if (total == 0x7ffffff0) {\n#else\n        if (total) {\n#endif\n            const unsigned long long my_start")
+sub("        if (fm) {\n", "#ifdef ABL_T_NOSTAGE\n        if (fm == 0x7ffffff0) {\n#else\n        if (fm) {\n#endif\n")
+sub("        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {",
+    "#ifdef ABL_T_NOCOOP\n        for (uint64_t mb = __ballot(npx == 0x7ffffff0); mb; mb &= mb - 1) {\n#else\n"
+    "        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {\n#endif")
 sub("            const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];",
     "#ifdef ABL_T_NOWINNER\n            const uint4 tail = {r, r, r, 0u};\n#else\n"
     "            const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];\n#endif")
-sub("                const bool act = small && k < npx;", "#ifdef ABL_T_NOSMALL\n                const bool act = false;\n#else\n                const bool act = small && k < npx;\n#endif")
-sub("        for (uint64_t mb = __ballot(npx != 0 && !small); mb; mb &= mb - 1) {", "#ifdef ABL_T_NOCOOP\n        for (uint64_t mb = 0; mb; mb &= mb - 1) {\n#else\n        for (uint64_t mb = __ballot(npx != 0 && !small); mb; mb &= mb - 1) {\n#endif")
-sub("                            atomicMax(&s_key[cy * MTR_BIN + cx], make_key(z, s.t.ordk));", "#ifdef ABL_T_NOATOM\n                            s_key[cy * MTR_BIN + cx] = make_key(z, s.t.ordk);\n#else\n                            atomicMax(&s_key[cy * MTR_BIN + cx], make_key(z, s.t.ordk));\n#endif")
 open(os.path.join(R, "tools/abl/k_tile_vis_abl.hip"), "w").write(s)

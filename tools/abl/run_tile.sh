@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT/mt_renderer_amd/csrc
 cp ../../tools/abl/k_tile_vis_abl.hip ./k_tile_vis_abl.hip
-for v in "ABL_T_NOSMALL" "ABL_T_NOCOOP" "ABL_T_NOATOM" "VIS_WAVES=4" "VIS_WAVES=1"; do
+for v in "ABL_T_NOFLAT" "ABL_T_NOSTAGE" "ABL_T_NOCOOP" "ABL_T_NOSTAGE -DABL_T_NOCOOP" "ABL_T_NOSETUP" "ABL_T_NOSETUP -DABL_T_NOWINNER"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-missing-braces -D$v -c k_tile_vis_abl.hip -o k_tile_vis.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr.so k_geom.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o
   cd ../..
