@@ -409,3 +409,21 @@ def test_single_pass_queue_overflow_falls_back(gpu_device):
         assert g[2]["binning"] == 1
     finally:
         gpu_device.set_binning(True, 1024)
+
+
+@pytest.mark.gpu
+def test_visibility_kernel_many_bin_filling_triangles(gpu_device):
+    """150 opaque quads of 20..60 px (i32 edge class) stacked over a 64x64 target at random depths, some of them
+    equal: every bin holds hundreds of triangles that each cover all 256 of its pixels, so a pass of the
+    visibility kernel's flattened walk spans many 4096-pair rounds and 64-pair batches, and depth ties are
+    decided by submission order."""
+    rng = np.random.default_rng(7)
+    prims = []
+    for q in range(150):
+        sz = rng.uniform(20, 60)
+        x0, y0 = rng.uniform(-10, 50), rng.uniform(-10, 50)
+        z = float(rng.integers(1, 9)) / 16.0
+        prims.append(dict(verts=[(x0, y0, z), (x0, y0 + sz, z), (x0 + sz, y0 + sz, z), (x0 + sz, y0, z)],
+                          indices=[0, 1, 2, 0, 2, 3], debug_id=q))
+    g = _px(gpu_device, prims, w=64, h=64)
+    assert g[2]["tile_kernel"] == 2 and g[2]["bin_entries"] > 16 * 100, g[2]
