@@ -69,6 +69,15 @@ def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the HIP draw path)")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If libmtr.so maps the system runtime
+    # first and torch is imported later, the process ends up with two HSA runtimes and torch reports "No HIP GPUs
+    # are available"; with torch mapped first, libmtr.so binds to the runtime that is already there.  So: when
+    # torch is installed, load it before the library (MTR_NO_TORCH_PRELOAD=1 skips this).
+    if os.environ.get("MTR_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, sz = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t
     sig = {

@@ -54,7 +54,8 @@ def render_gpu(dev, w, h, draws, clear=(1.0, 1.0, 1.0, 1.0), clear_depth=1.0, sh
                 fr.draw_overlay_cubes(d["vp"], d["overlay"])
                 continue
             if id(md) not in models:
-                models[id(md)] = api.Model.new(dev, md)
+                # "make_model": build the api.Model some other way (e.g. from resource files) for the same md
+                models[id(md)] = d["make_model"](dev) if "make_model" in d else api.Model.new(dev, md)
             m = models[id(md)]
             if "model_mats" in d:
                 b = api.Batch(dev, m, d["model_mats"], d.get("palettes"), d.get("tex_override"))

@@ -1,0 +1,257 @@
+"""Test-side WRITERS of the MT Framework resource files (the product only reads them): synthetic .mod / .tex / .mfx /
+.mrl / .sdl images laid out as the reference's readers expect (struct layouts: src/rmodel.rs:84-171,
+src/rtexture.rs:24-48, src/rshader2.rs:14-66 + :181-186, src/rmaterial.rs:12-116, src/rscheduler.rs:36-79).
+
+The reference ships no asset files (they are the game's), so there is no golden file to pin full-file parsing on:
+"parity unpinned" beyond the struct-size tests, the crc32 / DTI-hash known answers and the bit-field accessors,
+which tests/test_files.py checks against the reference's own numbers."""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from mt_renderer_amd import scene
+
+CRC_POLY = 0xEDB88320
+
+
+def crc32_mt(data: bytes, init: int = 0xFFFFFFFF) -> int:
+    """MT crc32: standard reflected table, no final xor, stops at a NUL byte (src/util/crc.rs:36-50).  Independent of
+    the library's implementation on purpose."""
+    val = init
+    for b in data:
+        if b == 0:
+            break
+        val ^= b
+        for _ in range(8):
+            val = (val >> 1) ^ (CRC_POLY if val & 1 else 0)
+    return val & 0xFFFFFFFF
+
+
+def handle_of(name: str, low: int = 0x123) -> int:
+    """An object handle: name hash (20 bits) << 12 | 12 bits the lookup ignores (src/rshader2.rs:487-492)."""
+    return ((crc32_mt(name.encode()) & 0xFFFFF) << 12) | (low & 0xFFF)
+
+
+def _pad(b: bytearray, align: int = 16):
+    while len(b) % align:
+        b.append(0)
+
+
+# ------------------------------------------------------------------------------------------------ rTexture
+def write_rtexture(width: int, height: int, fmt: int, data: bytes, prebias: int = 0, tex_type: int = 2,
+                   level_count: int = 1, array_count: int = 1, magic: bytes = b"TEX\0", version: int = 0x9D) -> bytes:
+    assert width % (1 << prebias) == 0 and height % (1 << prebias) == 0
+    b4 = (version & 0xFFFF) | ((prebias & 0xF) << 24) | ((tex_type & 0xF) << 28)
+    b8 = (level_count & 0x3F) | (((width >> prebias) & 0x1FFF) << 6) | (((height >> prebias) & 0x1FFF) << 19)
+    bc = (array_count & 0xFF) | ((fmt & 0xFF) << 8) | (1 << 16)
+    n = array_count * level_count
+    hdr = magic + struct.pack("<III", b4, b8, bc)
+    off0 = 16 + 8 * n
+    offs = b"".join(struct.pack("<Q", off0 + i * 0) for i in range(n))  # only offsets[0] is read (src/rtexture.rs:126)
+    return hdr + offs + data
+
+
+# ------------------------------------------------------------------------------------------------ rShader2
+SEM_NAMES = {scene.SEM_POSITION: "Position", scene.SEM_TEXCOORD: "TexCoord", 2: "Joint", 3: "Weight"}
+
+
+def write_rshader2(objects: Sequence[dict], magic: int = 0x58464D) -> bytes:
+    """objects: dicts {name, obj_type, [stride, elements=[(name, fmt, count, offset, sindex)]]}"""
+    strings = bytearray(b"\0")  # offset 0 = "no name"
+    str_off: Dict[str, int] = {}
+
+    def s(name: str) -> int:
+        if name not in str_off:
+            str_off[name] = len(strings)
+            strings.extend(name.encode() + b"\0")
+        return str_off[name]
+
+    n = len(objects)
+    body = bytearray()
+    ptrs = []
+    base = 0x20 + 8 * n
+    for o in objects:
+        _pad(body, 8)
+        ptrs.append(base + len(body))
+        b10 = o["obj_type"] & 0x3F
+        b14 = (o.get("sindex", 0) & 0xFFFF) | ((o.get("index", 0) & 0xFFFF) << 16)
+        body += struct.pack("<QQIIIIQ", s(o["name"]), 0, b10, b14, 0, 0, 0)
+        if o["obj_type"] == 9:
+            els = o["elements"]
+            body += struct.pack("<IIQ", (len(els) & 0xFFFF) | ((o["stride"] & 0xFFFF) << 16), 0, 0)
+            for (name, fmt, count, offset, sindex) in els:
+                bits = (sindex & 0x3F) | ((fmt & 0x1F) << 6) | ((count & 0x7F) << 11) | ((offset & 0x1FF) << 22)
+                body += struct.pack("<QII", s(name), bits, 0)
+        elif o["obj_type"] == 0:
+            body += struct.pack("<IIQQ", 0, 0, 0, 0)
+        elif o["obj_type"] == 8:
+            body += struct.pack("<IIQ", 0, 0, 0)
+    strtab = base + len(body)
+    hdr = struct.pack("<IHHIIQQ", magic, 1, 0, 0x1234, n + 1, strtab, 0)
+    return hdr + b"".join(struct.pack("<Q", p) for p in ptrs) + bytes(body) + bytes(strings)
+
+
+# ----------------------------------------------------------------------------------------------- rMaterial
+RTEXTURE_DTI = crc32_mt(b"rTexture") & 0x7FFFFFFF
+
+
+def write_rmaterial(textures: Sequence[str], materials: Sequence[dict], texture_dti: int = RTEXTURE_DTI) -> bytes:
+    """materials: dicts {name, albedo (1-based texture index or None), bs, ds, rs (state object names),
+    extra_states=[(type, sh_obj_name, value)]}"""
+    nt, nm = len(textures), len(materials)
+    tex_off = 0x28
+    mat_off = tex_off + nt * 0x98
+    st_off = mat_off + nm * 0x48
+    out = bytearray(struct.pack("<IIIIIIQQ", 0x4C524D, 0x22, nm, nt, 0x1234, 0, tex_off, mat_off))
+    for path in textures:
+        out += struct.pack("<IIQQ", texture_dti, 0, 0, 0) + path.encode().ljust(128, b"\0")
+    states = bytearray()
+    infos = bytearray()
+    for m in materials:
+        sts = list(m.get("extra_states", []))
+        if m.get("albedo") is not None:
+            sts.append((3, "tAlbedoMap", m["albedo"]))
+        first = st_off + len(states)
+        for (stype, obj, value) in sts:
+            b0 = (stype & 0xF) | ((m.get("group", 1) & 0xFFFF) << 4)
+            states += struct.pack("<IIQII", b0, 0, value, handle_of(obj), 0)
+        infos += struct.pack("<IIIIIIIII4fIQQ", crc32_mt(b"nDraw::MaterialStd") & 0x7FFFFFFF, 0, crc32_mt(m["name"].encode()),
+                             len(sts) * 0x18, handle_of(m.get("bs", "BSSolid")), handle_of(m.get("ds", "DSZTestWrite")),
+                             handle_of(m.get("rs", "RSMesh")), len(sts) & 0xFFF, 0, 1.0, 1.0, 1.0, 1.0, 0, first, 0)
+    return bytes(out + infos + states)
+
+
+# -------------------------------------------------------------------------------------------------- rModel
+def write_rmodel(md: scene.ModelData, prim_layout_handle: Sequence[int], material_names: Sequence[str],
+                 prim_material: Sequence[int], joints: Optional[Sequence[Tuple[int, int, Tuple[float, float, float]]]] = None,
+                 lmats: Optional[np.ndarray] = None, imats: Optional[np.ndarray] = None) -> bytes:
+    """One boundary info per primitive (joint = the primitive's debug id).  Sections are laid out in an order that
+    differs from the header's field order, with padding, to exercise the offsets."""
+    np_ = md.nprims
+    assert np_ <= 255
+    prims = np.ascontiguousarray(md.prims, dtype=np.uint8).reshape(-1, 0x38).copy()
+    for p in range(np_):
+        w = prims[p].view("<u4")
+        w[1] = (w[1] & ~np.uint32(0xFFF << 12)) | np.uint32((prim_material[p] & 0xFFF) << 12)
+        w[5] = np.uint32(prim_layout_handle[p])
+        w[9] = (w[9] & ~np.uint32(0xFF << 8)) | np.uint32((p & 0xFF) << 8)
+    jn = len(joints) if joints else 0
+    body = bytearray()
+    base = 0xA0 + 4
+
+    def put(b: bytes, align: int = 16) -> int:
+        while (base + len(body)) % align:
+            body.append(0)
+        off = base + len(body)
+        body.extend(b)
+        return off
+
+    vertex_data = put(np.ascontiguousarray(md.vertex_buf, dtype=np.uint8).tobytes())
+    mats = b"".join(n.encode().ljust(128, b"\0") for n in material_names)
+    material_info = put(mats)
+    bnd = bytearray()
+    for p in range(np_):
+        bnd += struct.pack("<I3I", int(md.prim_debug_id[p]), 0, 0, 0) + bytes(0x90 - 16)
+    primitive_info = put(prims.tobytes() + bytes(bnd), 8)  # boundary infos follow the primitive array
+    joint_info = 0
+    if jn:
+        ji = b"".join(struct.pack("<Iff3f", (no & 0xFF) | ((parent & 0xFF) << 8) | (0xFF << 16), 1.0, 2.0, *off) for (no, parent, off) in joints)
+        lm = np.ascontiguousarray(lmats, dtype="<f4").reshape(jn, 16).tobytes()
+        im = np.ascontiguousarray(imats, dtype="<f4").reshape(jn, 16).tobytes()
+        table = bytes([i if i < jn else 255 for i in range(256)])
+        joint_info = put(ji + lm + im + table, 8)
+    parts_n = int(max(scene.unpack_primitive(md.prims[p])["parts_no"] for p in range(np_))) + 1 if np_ else 0
+    parts = b"".join(struct.pack("<I3I4f", i, 0, 0, 0, 0.0, 0.0, 0.0, 1.0) for i in range(parts_n))
+    parts_info = put(parts)
+    index_data = put(np.ascontiguousarray(md.index_buf, dtype="<u2").tobytes(), 2)
+    vnum = sum(scene.unpack_primitive(md.prims[p])["vertex_num"] for p in range(np_))
+    hdr = struct.pack("<IHHHHIIIIIIIQQQQQQQ4f4f4fiiIHH", 0x444F4D, 0xD3, jn, np_, len(material_names), vnum, md.index_buf.size,
+                      md.input_triangles(), md.vertex_buf.size, 0, parts_n, 0, joint_info, parts_info, material_info, primitive_info,
+                      vertex_data, index_data, 0, 0.0, 0.0, 0.0, 10.0, -1.0, -1.0, -1.0, 0.0, 1.0, 1.0, 1.0, 0.0, 100, 200, 0, 0, 0)
+    assert len(hdr) == 0xA0
+    return hdr + struct.pack("<I", np_) + bytes(body)
+
+
+def files_from_model_data(md: scene.ModelData, texture_paths: Optional[Sequence[str]] = None):
+    """ModelData -> (rmodel, rshader2, rmaterial, [rtexture...]) byte strings describing the same model the way
+    real assets would: layouts become shader-package input layouts (plus elements the draw path must ignore),
+    prim_to_texture goes through material name -> rMaterial -> tAlbedoMap, debug ids through boundary joints."""
+    layouts: List[tuple] = []
+    prim_layout = []
+    for p in range(md.nprims):
+        key = (tuple(md.layouts[p]), scene.unpack_primitive(md.prims[p])["vertex_stride"])
+        if key not in layouts:
+            layouts.append(key)
+        prim_layout.append(layouts.index(key))
+    objects = [dict(name="BSSolid", obj_type=4), dict(name="DSZTestWrite", obj_type=5), dict(name="RSMesh", obj_type=6),
+               dict(name="tAlbedoMap", obj_type=1), dict(name="SSLinear", obj_type=3), dict(name="CBMaterial", obj_type=0)]
+    for i, (els, stride) in enumerate(layouts):
+        e = [("Normal", scene.IEF_S8N if hasattr(scene, "IEF_S8N") else 9, 3, 0, 0)]  # not bound by the draw path
+        e += [(SEM_NAMES[sem], fmt, cnt, off, 0) for (sem, fmt, cnt, off) in els]
+        e.append(("Tangent", 11, 1, 0, 0))                                            # SCMP3N: skipped
+        objects.append(dict(name=f"IATest{i}", obj_type=9, stride=stride, elements=e))
+    rshader2 = write_rshader2(objects)
+    ntex = len(md.textures)
+    paths = list(texture_paths) if texture_paths is not None else [f"model\\tex\\t{i}_BM" for i in range(ntex)]
+    names = [f"mat_{p}" for p in range(md.nprims)]
+    mats = []
+    for p in range(md.nprims):
+        t = int(md.prim_to_texture[p])
+        mats.append(dict(name=names[p], albedo=(t + 1) if t >= 0 else None, extra_states=[(2, "SSLinear", handle_of("SSLinear")),
+                                                                                            (1, "CBMaterial", 0)]))
+    rmaterial = write_rmaterial(paths, mats)
+    rmodel = write_rmodel(md, [handle_of(f"IATest{i}", low=p) for p, i in enumerate(prim_layout)], names, list(range(md.nprims)))
+    rtextures = [write_rtexture(t.width, t.height, t.fmt, t.data) for t in md.textures]
+    return rmodel, rshader2, rmaterial, rtextures
+
+
+# ---------------------------------------------------------------------------------------------- rScheduler
+def write_rscheduler(tracks: Sequence[dict], version: int = 0x16, magic: bytes = b"SDL\0") -> bytes:
+    """tracks: dicts {type, prop, name, [field_10], keys=[(frame, mode, value)]}; value: bool / int / float, or for
+    RESOURCE tracks None or (class_hash, path)."""
+    n = len(tracks)
+    trk_off = 0x20
+    data = bytearray()
+    base = trk_off + n * 0x30
+    meta = bytearray(b"\0\0\0\0")  # metadata block: names and resource references (offset 0 = null)
+    recs = []
+    for t in tracks:
+        name_off = len(meta)
+        meta += t["name"].encode() + b"\0"
+        keys = t.get("keys", [])
+        kf = kv = 0
+        if keys:
+            _pad(data, 8)
+            kf = base + len(data)
+            for (frame, mode, _v) in keys:
+                data += struct.pack("<I", (frame & 0xFFFFFF) | ((mode & 0xFF) << 24))
+            _pad(data, 8)
+            kv = base + len(data)
+            for (_f, _m, v) in keys:
+                tt = t["type"]
+                if tt == 11:
+                    data += struct.pack("<B", 1 if v else 0)
+                elif tt == 6:
+                    data += struct.pack("<I", v & 0xFFFFFFFF)
+                elif tt == 9:
+                    data += struct.pack("<f", v)
+                elif tt == 13:
+                    if v is None:
+                        data += struct.pack("<Q", 0)
+                    else:
+                        _pad(meta, 4)
+                        data += struct.pack("<Q", len(meta))
+                        meta += struct.pack("<I", v[0]) + v[1].encode() + b"\0"
+                else:
+                    data += struct.pack("<4f", *v)
+        recs.append((t, name_off, kf, kv, len(keys)))
+    _pad(data, 8)
+    metadata = base + len(data)
+    out = bytearray(magic + struct.pack("<HHIIIIQ", version, n, 0xABCD, 0, 0, 0, metadata))
+    for (t, name_off, kf, kv, nk) in recs:
+        b0 = (t["type"] & 0xFF) | ((t.get("prop", 0) & 0xFF) << 8) | ((nk & 0xFFFF) << 16)
+        out += struct.pack("<IIQIIQQQ", b0, t.get("parent", 0), name_off, t.get("field_10", 0), 0, 0, kf, kv)
+    return bytes(out + data + meta)

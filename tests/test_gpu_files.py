@@ -1,0 +1,74 @@
+"""-m gpu: Model::new over resource FILES (mtr_model_create_from_files, src/model.rs:36-293) renders bit for bit what
+the oracle renders from the same model given directly: layouts resolved through the shader package by handle,
+textures through material name -> rMaterial -> tAlbedoMap, debug ids through boundary joints, textures uploaded from
+.tex images (RGBA8 / BC1 / BC7)."""
+import numpy as np
+import pytest
+
+from mt_renderer_amd import api, files, scene
+from tests import mt_files
+from tests.helpers import assert_same, render_gpu, render_oracle
+from tests.pixel_scenes import pixel_model, pixel_to_ndc_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _from_files(md, drop_texture=None):
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+
+    def make(dev):
+        sh = files.Shader2File(rshader2)
+        mat = files.MaterialFile(rmaterial, sh)
+        assert len(mat.textures()) == len(rtextures)
+        tex = [None if i == drop_texture else files.TextureFile(b).upload(dev) for i, b in enumerate(rtextures)]
+        return files.model_from_files(dev, files.ModelFile(rmodel), sh, mat, tex)
+    return make
+
+
+def test_pixel_model_from_files(gpu_device):
+    tex = [scene.checker_rgba8_texture(16, 16, alpha=(255, 120)), scene.random_bc1_texture(8, 8), scene.random_bc7_texture(16, 16, seed=5)]
+    prims = [dict(verts=[(1, 1, .5, 0, 0), (1, 60, .5, 0, 1), (60, 60, .5, 1, 1)], indices=[0, 1, 2], texture=1, debug_id=7),
+             dict(verts=[(2, 2, .25), (2, 40, .25), (40, 2, .25), (40, 40, .25)], indices=[0, 1, 2, 3], topology=scene.TOPO_STRIP,
+                  debug_id=3, parts_no=1),
+             dict(verts=[(5, 5, .75, .5, .5), (5, 55, .75, .5, 1), (55, 55, .75, 1, 1)], indices=[0, 1, 2], texture=0, debug_id=11),
+             dict(verts=[(30, 3, .1, 0, 0), (30, 33, .1, 0, 1), (62, 33, .1, 1, 1)], indices=[0, 1, 2], texture=2, debug_id=19)]
+    md = pixel_model(prims, textures=tex)
+    M = pixel_to_ndc_matrix(64, 64)
+    ref = render_oracle(64, 64, [dict(md=md, M=M)])
+    got = render_gpu(gpu_device, 64, 64, [dict(md=md, M=M, make_model=_from_files(md))])
+    assert_same(got, ref, "pixel model from files")
+
+
+def test_skinned_textured_mesh_from_files(gpu_device):
+    W, H = 320, 200
+    md = scene.mesh50k(textured=True, textures=[scene.random_bc7_texture(64, 64, seed=9)], rows=12, cols=20)
+    M = scene.to_f32_colmajor(scene.headline_transform(W, H))
+    pal = scene.bone_palette()
+    ref = render_oracle(W, H, [dict(md=md, M=M, palette=pal)])
+    got = render_gpu(gpu_device, W, H, [dict(md=md, M=M, palette=pal, make_model=_from_files(md))])
+    assert_same(got, ref, "skinned mesh from files")
+
+
+def test_unloaded_texture_is_an_error_only_when_needed(gpu_device):
+    tex = [scene.checker_rgba8_texture(8, 8), scene.checker_rgba8_texture(8, 8)]
+    prims = [dict(verts=[(1, 1, .5, 0, 0), (1, 30, .5, 0, 1), (30, 30, .5, 1, 1)], indices=[0, 1, 2], texture=1)]
+    md = pixel_model(prims, textures=tex)
+    m = _from_files(md, drop_texture=0)(gpu_device)  # texture 0 failed to load, nothing uses it: fine (src/model.rs:46-58)
+    m.close()
+    with pytest.raises(api.MtrError) as e:           # texture 1 is the primitive's albedo: "no texture found!" (src/model.rs:167)
+        _from_files(md, drop_texture=1)(gpu_device)
+    assert e.value.code == api.MTR_E_INVALID and "no texture found" in str(e.value)
+
+
+def test_unknown_input_layout_handle_is_an_error(gpu_device):
+    md = pixel_model([dict(verts=[(1, 1, .5), (1, 30, .5), (30, 30, .5)], indices=[0, 1, 2])])
+    rmodel, rshader2, rmaterial, _ = mt_files.files_from_model_data(md)
+    bad = mt_files.write_rmodel(md, [mt_files.handle_of("IANotThere")], ["mat_0"], [0])
+    sh = files.Shader2File(rshader2)
+    with pytest.raises(api.MtrError) as e:  # panic!("invalid inputlayout ..."), src/model.rs:182-183
+        files.model_from_files(gpu_device, files.ModelFile(bad), sh, files.MaterialFile(rmaterial, sh), [])
+    assert "invalid inputlayout" in str(e.value)
+    # a handle that names a non-layout object: unreachable!() in the reference
+    bad = mt_files.write_rmodel(md, [mt_files.handle_of("RSMesh")], ["mat_0"], [0])
+    with pytest.raises(api.MtrError):
+        files.model_from_files(gpu_device, files.ModelFile(bad), sh, None, [])
