@@ -173,11 +173,11 @@ def main():
     dom = max(stage_ms, key=lambda k: stage_ms[k])
     alg_bytes = algorithmic_bytes(md, W, H, 1)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    kname = {"geom": "k_geom<%s>" % ("true" if stats["binning"] == 1 else "false"), "scan": "k_scan", "fill": "k_fill",
+    kname = {"geom": "k_geom<%d>" % ((2 if stats["tile_kernel"] == 2 else 1) if stats["binning"] == 1 else 0), "scan": "k_scan", "fill": "k_fill",
              "tile": "k_tile_vis<false>" if stats["tile_kernel"] == 2 else "k_tile<false>"}[dom]
     # HBM bytes of that kernel per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
     # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md); measured offline, see profiles/README.md
-    traffic = {"k_tile_vis<false>": TRAFFIC_TILE_VIS, "k_geom<true>": TRAFFIC_GEOM_DIRECT}.get(kname) if world == 1 else None
+    traffic = {"k_tile_vis<false>": TRAFFIC_TILE_VIS, "k_geom<2>": TRAFFIC_GEOM_DIRECT}.get(kname) if world == 1 else None
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 5),

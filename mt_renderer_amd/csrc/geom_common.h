@@ -359,4 +359,135 @@ __device__ __forceinline__ void emit_bins(const FrameBuffers& fb, RecHdr h, bool
         });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-pass binning for frames the visibility-key tile kernel renders (every material opaque): the winner of a
+// pixel does not depend on the order of the queue, so there is no order to keep and no segment to describe.
+// Groups form around the FIRST ACTIVE lane's current bin (one v_readlane instead of a wave-wide minimum); a bin may
+// then be served more than once per round, which only costs one more reservation.  Same queues, same fill words
+// (entries in the low half, reservations in the high half) as the ordered builder.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short mtr_us2 __attribute__((ext_vector_type(2)));
+// both 16-bit halves at once (v_pk_min_u16 / v_pk_max_u16): wave-wide minimum / maximum of a packed (x, y) pair
+template <bool MAX>
+__device__ __forceinline__ uint32_t pk_minmax(uint32_t a, uint32_t b) {
+    const mtr_us2 x = __builtin_bit_cast(mtr_us2, a), y = __builtin_bit_cast(mtr_us2, b);
+    return __builtin_bit_cast(uint32_t, MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y));
+}
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_pk_minmax(uint32_t v) {
+    v = pk_minmax<MAX>(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false));
+    v = pk_minmax<MAX>(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false));
+    v = pk_minmax<MAX>(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false));
+    v = pk_minmax<MAX>(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false));
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return __builtin_amdgcn_readfirstlane(pk_minmax<MAX>(pk_minmax<MAX>(r0, r1), pk_minmax<MAX>(r2, r3)));
+}
+
+// `slot`: 128 dwords of LDS private to the wave (entry counts, then queue offsets, of an 8x8 window of bins).
+__device__ __forceinline__ void emit_bins_unordered(const FrameBuffers& fb, RecHdr h, bool act, uint32_t gid, uint32_t round, uint32_t lane,
+                                                    uint32_t* slot) {
+    const uint32_t ord0 = gid * 128u + round * 64u;
+    const uint32_t nb = act ? (uint32_t)(h.bx1 - h.bx0 + 1) * (uint32_t)(h.by1 - h.by0 + 1) : 0u;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    // ---- fast path, lane-parallel: every record covers <= 4 bins and the round's bins fit an 8x8 window (a strip
+    //      chunk of small triangles always does).  Each lane counts itself into the LDS slot of each of its bins
+    //      (the returned count is its place in the group), lane s then reserves queue space for slot s with one
+    //      global atomic, and every lane stores its entries: no loop over groups at all. ----
+    {
+        const uint32_t lo = wave_pk_minmax<false>(act ? ((uint32_t)h.bx0 | ((uint32_t)h.by0 << 16)) : 0xFFFFFFFFu);
+        const uint32_t hi = wave_pk_minmax<true>(act ? ((uint32_t)h.bx1 | ((uint32_t)h.by1 << 16)) : 0u);
+        const uint32_t wx0 = lo & 0xffffu, wy0 = lo >> 16;
+        if (!__ballot(nb > 4u) && (hi & 0xffffu) - wx0 < 8u && (hi >> 16) - wy0 < 8u) {
+            const uint32_t w = (uint32_t)(h.bx1 - h.bx0) + 1u;  // 1..4; w >= 3 means a single row
+            slot[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t ranks = 0, own = 0;
+            for (uint32_t j = 0; j < 4u; j++) {
+                const bool on = j < nb;
+                if (!__ballot(on)) break;
+                const uint32_t dx = w == 1u ? 0u : (w == 2u ? (j & 1u) : j), dy = w == 1u ? j : (w == 2u ? (j >> 1) : 0u);
+                const uint32_t bx = h.bx0 + dx, by = h.by0 + dy;
+                if (on && bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world)) {
+                    ranks |= atomicAdd(&slot[(by - wy0) * 8u + (bx - wx0)], 1u) << (8u * j);
+                    own |= 1u << j;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t c = slot[lane];
+            if (c) {
+                const uint32_t bin = (wy0 + (lane >> 3)) * fb.nbx + wx0 + (lane & 7u);
+                uint32_t o = (uint32_t)atomicAdd(&fb.bin_fill[bin], (unsigned long long)c | (1ull << 32));
+                if (o + c > fb.qcap) { atomicOr(&fb.counters[CTR_OVERFLOW], 4u); o = 0x80000000u; }
+                slot[64 + lane] = o;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = 0; j < 4u; j++) {
+                if (!__ballot((own >> j) & 1u)) { if (!__ballot(j < nb)) break; continue; }
+                const uint32_t dx = w == 1u ? 0u : (w == 2u ? (j & 1u) : j), dy = w == 1u ? j : (w == 2u ? (j >> 1) : 0u);
+                const uint32_t bx = h.bx0 + dx, by = h.by0 + dy;
+                if ((own >> j) & 1u) {
+                    const uint32_t o = slot[64 + (by - wy0) * 8u + (bx - wx0)];
+                    if (!(o & 0x80000000u)) fb.entries[(by * fb.nbx + bx) * fb.qcap + o + ((ranks >> (8u * j)) & 0xffu)] = ord0 + lane;
+                }
+            }
+            // the next round (or the caller) may reuse the slots at once: LDS operations of one wave are ordered
+            return;
+        }
+    }
+    uint32_t gbin = 0, ng = 0;
+    uint64_t gmask = 0;
+    auto flush = [&]() {
+        if (ng == 0) return;
+        uint32_t off = 0;
+        if (lane < ng) {
+            const uint32_t cnt = (uint32_t)__popcll(gmask);
+            off = (uint32_t)atomicAdd(&fb.bin_fill[gbin], (unsigned long long)cnt | (1ull << 32));
+            if (off + cnt > fb.qcap) atomicOr(&fb.counters[CTR_OVERFLOW], 4u);
+        }
+        for (uint32_t gi = 0; gi < ng; gi++) {
+            const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gmask >> 32), gi) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gmask, gi);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, gi);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)gbin, gi);
+            if (((m >> lane) & 1ull) && o + (uint32_t)__popcll(m) <= fb.qcap)
+                fb.entries[b * fb.qcap + o + (uint32_t)__popcll(m & lt)] = ord0 + lane;
+        }
+        ng = 0;
+    };
+    bool a = act && nb <= MTR_WIDE_BINS;
+    uint32_t bx = h.bx0, by = h.by0;
+    while (a && !bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world)) {
+        if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) a = false; }
+    }
+    for (;;) {
+        const uint64_t m_act = __ballot(a);
+        if (!m_act) break;
+        const uint32_t mybin = by * fb.nbx + bx;
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mybin, (uint32_t)__ffsll((long long)m_act) - 1);
+        const bool hit = a && mybin == b;
+        const uint64_t m = __ballot(hit);
+        if (lane == ng) { gbin = b; gmask = m; }
+        if (++ng == 64) flush();
+        if (hit) {
+            do {
+                if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) a = false; }
+            } while (a && !bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world));
+        }
+    }
+    flush();
+    // big triangles: lane = bin of the rectangle, one reservation each
+    for (uint64_t mw = __ballot(nb > MTR_WIDE_BINS); mw; mw &= mw - 1) {
+        const uint32_t wl = (uint32_t)__ffsll((long long)mw) - 1;
+        for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin) {
+            const uint32_t o = (uint32_t)atomicAdd(&fb.bin_fill[bin], 1ull | (1ull << 32));
+            if (o < fb.qcap) fb.entries[bin * fb.qcap + o] = ord0 + wl;
+            else atomicOr(&fb.counters[CTR_OVERFLOW], 4u);
+        });
+    }
+}
+
 }  // namespace mtr

@@ -833,6 +833,10 @@ static int32_t run_frame(mtr_frame* f) {
     fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
     fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
     fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
+    // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a
+    // per-pixel (min z, latest) reduction and the visibility-key kernel applies; otherwise blend order matters
+    const bool use_vis = f->all_opaque && d->tile_mode != MTR_TILE_ORDERED;
+    fb.unordered = (f->ran_direct && use_vis) ? 1u : 0u;
 
     if (d->profiling && !f->have_events) {
         for (auto& e : f->ev) HIPCHK(d, hipEventCreate(&e));
@@ -879,9 +883,6 @@ static int32_t run_frame(mtr_frame* f) {
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
     bool any_textured = false;
     for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
-    // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a
-    // per-pixel (min z, latest) reduction and the visibility-key kernel applies; otherwise blend order matters
-    const bool use_vis = f->all_opaque && d->tile_mode != MTR_TILE_ORDERED;
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : MTR_TILE_ORDERED;
     if (use_vis) mtr_launch_tile_vis(tp, any_textured, st);
     else mtr_launch_tile(tp, any_textured, st);

@@ -104,6 +104,7 @@ struct FrameBuffers {
     // segs[b*scap ..), filled through bin_fill); overflow raises CTR_OVERFLOW bit 2 and the host re-runs the frame
     // with the exact two-pass (count, scan, fill) queues
     uint32_t direct, qcap, scap;
+    uint32_t unordered;             // direct mode only: the frame goes to the visibility-key kernel, queue order is free
 };
 
 // direct mode: the bin's workgroup is the only consumer of bin_fill[bin]; one thread parks the count in bin_count
