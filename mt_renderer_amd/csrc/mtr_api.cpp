@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -21,13 +22,21 @@ struct ColorDepth {
     uint8_t* color;
     float* depth;
     uint32_t* counters;
+    // recorded after the tile kernel of the last frame that rendered into these buffers; a frame that recycles
+    // them (possibly on another internal stream) waits on it before its first write
+    hipEvent_t done = nullptr;
+    bool used = false;
 };
 
 }  // namespace
 
-// Intermediate buffers of one frame in flight.  The device keeps two slots and two internal streams (geometry,
-// tile): frame k+1's geometry runs while frame k's tile kernel is still rasterising, which is what keeps a
-// latency-bound pipeline busy (DESIGN.md "frames in flight").  Grow-only.
+// Intermediate buffers of one frame in flight, and the internal stream its kernels run on.  The device keeps
+// `nslots` slots and deals frames to them round-robin: the kernels of one frame follow each other on one stream
+// with no cross-stream dependency in between, and the frames of different slots overlap (frame k+1's geometry runs
+// while frame k's tile kernel is still rasterising; DESIGN.md "frames in flight").  Grow-only.
+// 3 slots by default (headline scene, ms per frame: 1 slot 0.094, 2: 0.066, 3: 0.056, 4: 0.071, 6: 0.058); the environment
+// variable MTR_NSLOTS (1..MTR_MAX_SLOTS) overrides it at device creation.
+#define MTR_MAX_SLOTS 8
 struct Slot {
     RecHdr* rec_hdr = nullptr;
     RecA* rec_a = nullptr;
@@ -46,8 +55,7 @@ struct Slot {
     uint32_t mat_cap = 0;
     bool bin_fill_dirty = true;      // direct frames leave bin_fill zeroed (the tile kernels clean up); others do not
     std::vector<DMat> mats_uploaded;  // what `mats` currently holds: steady-state frames skip the upload
-    hipEvent_t tile_done = nullptr;   // recorded after the tile kernel of the last frame that used this slot
-    bool used = false;
+    hipStream_t stream = nullptr;     // a slot's frames are ordered by this stream: reuse needs no event
 };
 
 struct mtr_device {
@@ -57,9 +65,9 @@ struct mtr_device {
     bool profiling = false;
     int tile_mode = MTR_TILE_AUTO;
     std::string err;
-    Slot slots[2];
+    Slot slots[MTR_MAX_SLOTS];
+    uint32_t nslots = 3;
     uint32_t frame_counter = 0;
-    hipStream_t s_geom = nullptr, s_tile = nullptr;  // internal streams; `stream` joins them at every submit
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
     // two-pass queues and the bound is doubled for later frames
     bool direct_enabled = true;
@@ -139,7 +147,6 @@ struct mtr_frame {
     float ms[MTR_STAGE_COUNT] = {};
     int slot = 0;
     uint64_t min_entries = 0, min_segs = 0;  // queue sizes measured by a previous, overflowed attempt
-    hipEvent_t ev_geom = nullptr, ev_done = nullptr;  // geometry finished / framebuffer complete
 };
 
 namespace {
@@ -267,9 +274,11 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
         HIPCHK(nullptr, hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         d->own_stream = true;
     }
-    HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_geom, hipStreamNonBlocking));
-    HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_tile, hipStreamNonBlocking));
-    for (Slot& sl : d->slots) HIPCHK(nullptr, hipEventCreateWithFlags(&sl.tile_done, hipEventDisableTiming));
+    if (const char* e = getenv("MTR_NSLOTS")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= MTR_MAX_SLOTS) d->nslots = (uint32_t)v;
+    }
+    for (uint32_t i = 0; i < d->nslots; i++) HIPCHK(nullptr, hipStreamCreateWithFlags(&d->slots[i].stream, hipStreamNonBlocking));
     *out = d.release();
     return MTR_OK;
 }
@@ -282,23 +291,22 @@ void mtr_device_destroy(mtr_device* d) {
     if (!d) return;
     (void)hipSetDevice(d->hip_dev);
     (void)hipStreamSynchronize(d->stream);
-    if (d->s_geom) (void)hipStreamSynchronize(d->s_geom);
-    if (d->s_tile) (void)hipStreamSynchronize(d->s_tile);
+    for (Slot& sl : d->slots)
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     if (d->cube) mtr_model_destroy(d->cube);
     for (auto& f : d->free_fb) {
         (void)hipFree(f.color);
         (void)hipFree(f.depth);
         (void)hipFree(f.counters);
+        if (f.done) (void)hipEventDestroy(f.done);
     }
     for (Slot& sl : d->slots) {
         void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
                         sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
-        if (sl.tile_done) (void)hipEventDestroy(sl.tile_done);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
-    if (d->s_geom) (void)hipStreamDestroy(d->s_geom);
-    if (d->s_tile) (void)hipStreamDestroy(d->s_tile);
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -588,19 +596,30 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
     f->dev = d; f->w = w; f->h = h;
     f->clear_rgba8 = pack_rgba8(clear_rgba);
     f->clear_depth = clear_depth;
+    // recycle colour / depth buffers: prefer a set whose last frame has finished; while fewer than nslots + 1
+    // sets of this size are parked, allocate another rather than wait for one still in flight (a host that begins
+    // and destroys a frame per step would otherwise chain every frame to its predecessor)
     bool found = false;
+    size_t same = 0, oldest = SIZE_MAX, ready = SIZE_MAX;
     for (size_t i = 0; i < d->free_fb.size(); i++)
         if (d->free_fb[i].w == w && d->free_fb[i].h == h) {
-            f->fb = d->free_fb[i];
-            d->free_fb.erase(d->free_fb.begin() + (long)i);
-            found = true;
-            break;
+            same++;
+            if (oldest == SIZE_MAX) oldest = i;
+            if (ready == SIZE_MAX && (!d->free_fb[i].used || hipEventQuery(d->free_fb[i].done) == hipSuccess)) ready = i;
         }
+    (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
+    const size_t pick = ready != SIZE_MAX ? ready : (same > d->nslots ? oldest : SIZE_MAX);
+    if (pick != SIZE_MAX) {
+        f->fb = d->free_fb[pick];
+        d->free_fb.erase(d->free_fb.begin() + (long)pick);
+        found = true;
+    }
     if (!found) {
         f->fb.w = w; f->fb.h = h;
         if ((rc = dev_alloc(d, &f->fb.color, (size_t)w * h * 4))) return rc;
         if ((rc = dev_alloc(d, &f->fb.depth, (size_t)w * h))) return rc;
         if ((rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM))) return rc;
+        HIPCHK(d, hipEventCreateWithFlags(&f->fb.done, hipEventDisableTiming));
     }
     *out = f.release();
     return MTR_OK;
@@ -613,9 +632,7 @@ void mtr_frame_destroy(mtr_frame* f) {
     if (f->have_events)
         for (auto& e : f->ev)
             if (e) (void)hipEventDestroy(e);
-    if (f->ev_geom) (void)hipEventDestroy(f->ev_geom);
-    if (f->ev_done) (void)hipEventDestroy(f->ev_done);
-    // stream order protects the buffers: a later frame's kernels run after this frame's
+    // the buffers may still be written by this frame's kernels: whoever recycles them waits on fb.done
     d->free_fb.push_back(f->fb);
     delete f;
 }
@@ -732,13 +749,9 @@ static int32_t run_frame(mtr_frame* f) {
         tris_in += m->ntris_visible * dr.ninst;
     }
     if (total_chunks > 0x3FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
-    // this frame's slot: the other slot may still be feeding the previous frame's tile kernel
-    f->slot = (int)(d->frame_counter++ & 1u);
+    // this frame's slot: the other slots may still be feeding earlier frames' tile kernels
+    f->slot = (int)(d->frame_counter++ % d->nslots);
     Slot& sl = d->slots[f->slot];
-    if (!f->ev_done) {
-        HIPCHK(d, hipEventCreateWithFlags(&f->ev_geom, hipEventDisableTiming));
-        HIPCHK(d, hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
-    }
     const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
     if (rec_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many triangles in one frame");
     if (rec_need > sl.rec_cap || !sl.rec_a) {
@@ -821,7 +834,7 @@ static int32_t run_frame(mtr_frame* f) {
     }
     // the material table is tiny; the copy is ordered on the stream before the kernels that read it
     if (mats.size() != sl.mats_uploaded.size() || memcmp(mats.data(), sl.mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0) {
-        HIPCHK(d, hipMemcpyAsync(sl.mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, d->s_geom));
+        HIPCHK(d, hipMemcpyAsync(sl.mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, sl.stream));
         sl.mats_uploaded = mats;
     }
 
@@ -843,9 +856,10 @@ static int32_t run_frame(mtr_frame* f) {
         f->have_events = true;
     }
     const bool prof = d->profiling && f->have_events;
-    hipStream_t sg = d->s_geom, st = d->s_tile;
-    // slot reuse: the geometry of this frame overwrites what the tile kernel of frame k-2 read
-    if (sl.used) HIPCHK(d, hipStreamWaitEvent(sg, sl.tile_done, 0));
+    // one stream per slot: the slot's previous frame is ordered before this one by the stream itself
+    hipStream_t sg = sl.stream, st = sl.stream;
+    // recycled colour / depth / counter buffers: their last frame may have run on another slot's stream
+    if (f->fb.used) HIPCHK(d, hipStreamWaitEvent(sg, f->fb.done, 0));
     HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), sg));
     if (!fb.direct) {
         HIPCHK(d, hipMemsetAsync(sl.bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), sg));
@@ -875,8 +889,6 @@ static int32_t run_frame(mtr_frame* f) {
     if (!fb.direct) mtr_launch_scan(fb, sg);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[2], sg));
     if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, sg);
-    HIPCHK(d, hipEventRecord(f->ev_geom, sg));
-    HIPCHK(d, hipStreamWaitEvent(st, f->ev_geom, 0));
     if (prof) HIPCHK(d, hipEventRecord(f->ev[3], st));
     TileParams tp{};
     tp.fb = fb; tp.mats = sl.mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
@@ -887,11 +899,10 @@ static int32_t run_frame(mtr_frame* f) {
     if (use_vis) mtr_launch_tile_vis(tp, any_textured, st);
     else mtr_launch_tile(tp, any_textured, st);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
-    HIPCHK(d, hipEventRecord(sl.tile_done, st));
-    HIPCHK(d, hipEventRecord(f->ev_done, st));
-    sl.used = true;
+    HIPCHK(d, hipEventRecord(f->fb.done, st));
+    f->fb.used = true;
     // the device's public stream (read-backs, shard packing, the caller's own work) sees the framebuffer complete
-    HIPCHK(d, hipStreamWaitEvent(d->stream, f->ev_done, 0));
+    HIPCHK(d, hipStreamWaitEvent(d->stream, f->fb.done, 0));
     HIPCHK(d, hipGetLastError());
     {
         const uint32_t tk = f->stats.tile_kernel;

@@ -136,13 +136,16 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
     __syncthreads();
 }
 
-template <bool DIRECT>
+// MODE 0: count pass of the exact two-pass queues; 1: single-pass binning, ordered segments; 2: single-pass binning
+// for frames the visibility-key tile kernel renders (no order kept, no segments)
+template <int MODE>
 #ifndef GEOM_OCC
 #define GEOM_OCC 4  // waves per SIMD the register allocator must leave room for
 #endif
 __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
+    __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t inst = blockIdx.y;
@@ -325,7 +328,9 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         const bool act = j < total;
         RecHdr h = {0, 0, 0, 0};
         if (act) h = s_hdr[wave][j];
-        if (DIRECT) {
+        if (MODE == 2) {
+            emit_bins_unordered(P.fb, h, act, gid, round, lane, s_slot[wave]);
+        } else if (MODE == 1) {
             emit_bins<true>(P.fb, h, act, gid, round, lane);
         } else {
             count_bins(P.fb, h, act, lane);
@@ -361,8 +366,9 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
 #define ABL_LDS 0
 #endif
     size_t lds = (size_t)p.npal * 64 + ABL_LDS;
-    if (p.fb.direct) hipLaunchKernelGGL(mtr::k_geom<true>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(mtr::k_geom<false>, grid, dim3(256), lds, s, p);
+    if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL(mtr::k_geom<2>, grid, dim3(256), lds, s, p);
+    else if (p.fb.direct) hipLaunchKernelGGL(mtr::k_geom<1>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(mtr::k_geom<0>, grid, dim3(256), lds, s, p);
 }
 
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s) {
