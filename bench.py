@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 # HBM bytes per launch of the two heaviest kernels on the headline scene, from rocprofv3 PMC passes run separately
 # (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B,
-# MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_b_pmc_*.csv).
-TRAFFIC_TILE_VIS = 55059046     # k_tile_vis<false>: 2 x 18333.8 KB fetched + 17101.0 KB written (framebuffer = 16.6 MB)
-TRAFFIC_GEOM_DIRECT = 49288396  # k_geom<true>:      2 x 7377.1 KB fetched + 33379.0 KB written (records + bin queues)
+# MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_d_pmc_headline.csv).
+TRAFFIC_TILE_VIS = 56598733     # k_tile_vis<false>: 2 x 19050.7 KB fetched + 17170.8 KB written (framebuffer = 16.6 MB)
+TRAFFIC_GEOM_DIRECT = 48254771  # k_geom<2>:         2 x 7479.8 KB fetched + 32164.2 KB written (records + bin queues)
 
 
 def algorithmic_bytes(md, width, height, npalettes, nbones=64):
@@ -155,19 +155,45 @@ def main():
     mtris = ntris / (ms_per_step * 1e-3) / 1e6
 
     # ---- roofline: per-stage hipEvent timing on the library's stream, separate from the timed region ----
+    # Same submission pattern as the timed region (frames in flight on the library's internal streams, nothing waited
+    # until several later frames are queued), with hipEvents around every kernel of every frame: the averages are the
+    # kernels' launch durations WHILE OVERLAPPING, which is what rocprofv3 --kernel-trace --stats reports for the
+    # same command (profiles/).  stage_ms_serial: the same kernels one frame at a time (nothing else on the GPU).
     dev.set_profiling(True)
     stage_ms = {k: 0.0 for k in api.STAGE_NAMES}
-    nprof = max(5, min(50, args.steps))
+    nprof = max(8, min(100, args.steps))
+    depth = 6
     stats = None
+    inflight = []
+
+    def retire(fr):
+        nonlocal stats
+        fr.wait()
+        for k, v in fr.timings_ms().items():
+            stage_ms[k] += v / nprof
+        stats = fr.stats()
+        fr.close()
+
     for _ in range(nprof):
+        fr = api.Frame(dev, W, H)
+        if world > 1:
+            fr.set_shard(rank, world)
+        model.render(fr, M)
+        fr.submit()
+        inflight.append(fr)
+        if len(inflight) > depth:
+            retire(inflight.pop(0))
+    while inflight:
+        retire(inflight.pop(0))
+    stage_ms_serial = {k: 0.0 for k in api.STAGE_NAMES}
+    for _ in range(10):
         fr = api.Frame(dev, W, H)
         if world > 1:
             fr.set_shard(rank, world)
         model.render(fr, M)
         fr.end()
         for k, v in fr.timings_ms().items():
-            stage_ms[k] += v / nprof
-        stats = fr.stats()
+            stage_ms_serial[k] += v / 10
         fr.close()
     dev.set_profiling(False)
     dom = max(stage_ms, key=lambda k: stage_ms[k])
@@ -181,7 +207,9 @@ def main():
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 5),
-                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}}
+                "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
+                "stage_ms_serial": {k: round(v, 5) for k, v in stage_ms_serial.items()},
+                "frame_gbps": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 3)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -67,12 +68,20 @@ struct mtr_device {
     std::string err;
     Slot slots[MTR_MAX_SLOTS];
     uint32_t nslots = 3;
+    // host run-ahead bound: submitting frame i first waits (on the host) for frame i - max_inflight.  Without it a
+    // host that never waits queues thousands of commands and the runtime's per-call cost grows with the backlog
+    // and memory held by queued frames is unbounded.  Default 16 (no measurable cost); MTR_MAX_INFLIGHT overrides.
+    static constexpr uint32_t kMaxInflight = 64;
+    hipEvent_t inflight[kMaxInflight] = {};
+    uint32_t max_inflight = 16;
+    hipStream_t s_copy = nullptr;  // small read-backs of finished frames (statistics), independent of frames in flight
     uint32_t frame_counter = 0;
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
     // two-pass queues and the bound is doubled for later frames
     bool direct_enabled = true;
     uint32_t qcap = 1024, scap = 128;
     std::vector<ColorDepth> free_fb;
+    std::vector<std::pair<uint64_t, uint32_t>> fb_allocated;  // (w << 32 | h) -> colour / depth sets ever allocated
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
 };
 
@@ -279,6 +288,11 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
         if (v >= 1 && v <= MTR_MAX_SLOTS) d->nslots = (uint32_t)v;
     }
     for (uint32_t i = 0; i < d->nslots; i++) HIPCHK(nullptr, hipStreamCreateWithFlags(&d->slots[i].stream, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking));
+    if (const char* e = getenv("MTR_MAX_INFLIGHT")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= (long)mtr_device::kMaxInflight) d->max_inflight = (uint32_t)v;
+    }
     *out = d.release();
     return MTR_OK;
 }
@@ -293,6 +307,9 @@ void mtr_device_destroy(mtr_device* d) {
     (void)hipStreamSynchronize(d->stream);
     for (Slot& sl : d->slots)
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    for (hipEvent_t e : d->inflight)
+        if (e) (void)hipEventDestroy(e);
+    if (d->s_copy) (void)hipStreamDestroy(d->s_copy);
     if (d->cube) mtr_model_destroy(d->cube);
     for (auto& f : d->free_fb) {
         (void)hipFree(f.color);
@@ -596,9 +613,9 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
     f->dev = d; f->w = w; f->h = h;
     f->clear_rgba8 = pack_rgba8(clear_rgba);
     f->clear_depth = clear_depth;
-    // recycle colour / depth buffers: prefer a set whose last frame has finished; while fewer than nslots + 1
-    // sets of this size are parked, allocate another rather than wait for one still in flight (a host that begins
-    // and destroys a frame per step would otherwise chain every frame to its predecessor)
+    // recycle colour / depth buffers: prefer a set whose last frame has finished; while fewer than nslots + 2 sets
+    // of this size exist, allocate another rather than wait for one still in flight (a host that begins and
+    // destroys a frame per step would otherwise chain every frame to its predecessor)
     bool found = false;
     size_t same = 0, oldest = SIZE_MAX, ready = SIZE_MAX;
     for (size_t i = 0; i < d->free_fb.size(); i++)
@@ -608,7 +625,13 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
             if (ready == SIZE_MAX && (!d->free_fb[i].used || hipEventQuery(d->free_fb[i].done) == hipSuccess)) ready = i;
         }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error code
-    const size_t pick = ready != SIZE_MAX ? ready : (same > d->nslots ? oldest : SIZE_MAX);
+    // total sets of this size, parked or held by live frames: past nslots + 1 the pool stops growing as long as a
+    // parked set exists (its last frame is waited for on the device, not on the host)
+    uint32_t* total = nullptr;
+    for (auto& e : d->fb_allocated)
+        if (e.first == (((uint64_t)w << 32) | h)) total = &e.second;
+    if (!total) { d->fb_allocated.push_back({((uint64_t)w << 32) | h, 0u}); total = &d->fb_allocated.back().second; }
+    const size_t pick = ready != SIZE_MAX ? ready : ((same > 0 && *total > d->nslots) ? oldest : SIZE_MAX);
     if (pick != SIZE_MAX) {
         f->fb = d->free_fb[pick];
         d->free_fb.erase(d->free_fb.begin() + (long)pick);
@@ -620,6 +643,7 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
         if ((rc = dev_alloc(d, &f->fb.depth, (size_t)w * h))) return rc;
         if ((rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM))) return rc;
         HIPCHK(d, hipEventCreateWithFlags(&f->fb.done, hipEventDisableTiming));
+        ++*total;
     }
     *out = f.release();
     return MTR_OK;
@@ -750,6 +774,9 @@ static int32_t run_frame(mtr_frame* f) {
     }
     if (total_chunks > 0x3FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
     // this frame's slot: the other slots may still be feeding earlier frames' tile kernels
+    hipEvent_t& ring = d->inflight[d->frame_counter % d->max_inflight];
+    if (ring) HIPCHK(d, hipEventSynchronize(ring));  // frame (i - max_inflight) has left the GPU
+    else HIPCHK(d, hipEventCreateWithFlags(&ring, hipEventDisableTiming));
     f->slot = (int)(d->frame_counter++ % d->nslots);
     Slot& sl = d->slots[f->slot];
     const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
@@ -900,6 +927,7 @@ static int32_t run_frame(mtr_frame* f) {
     else mtr_launch_tile(tp, any_textured, st);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
     HIPCHK(d, hipEventRecord(f->fb.done, st));
+    HIPCHK(d, hipEventRecord(ring, st));
     f->fb.used = true;
     // the device's public stream (read-backs, shard packing, the caller's own work) sees the framebuffer complete
     HIPCHK(d, hipStreamWaitEvent(d->stream, f->fb.done, 0));
@@ -933,8 +961,10 @@ int32_t mtr_frame_wait(mtr_frame* f) {
     if (rc) return rc;
     for (int attempt = 0; attempt < 5; attempt++) {
         uint32_t ctr[CTR_NUM];
-        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->stream));
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        // wait for THIS frame only (the public stream also carries the completion of every later frame)
+        HIPCHK(d, hipEventSynchronize(f->fb.done));
+        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->s_copy));
+        HIPCHK(d, hipStreamSynchronize(d->s_copy));
         f->stats.tris_setup = 0;
         for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[MTR_CTR(CTR_REC, k)];
         f->stats.bin_entries = ctr[CTR_ENTRIES];
