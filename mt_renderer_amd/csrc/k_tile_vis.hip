@@ -170,6 +170,9 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     const uint32_t nbx = P.fb.nbx;
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
     const float cd = P.clear_depth;
+    // fragments pass 0 <= z <= 1 and z <= clear depth (nothing else is in the depth buffer before the resolve)
+    const bool zlim_ok = cd >= 0.0f;
+    const uint32_t zlim = __float_as_uint(fminf(cd, 1.0f));
     const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
     for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
     __syncthreads();
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         // ---- lane = (triangle, pixel) pair, 64 pairs per step, for every i32-class triangle.  A round stages a
         //      prefix of the remaining triangles holding <= 4096 pairs (64 start masks, one per lane); one round
         //      is the rule, a pass of 64 bin-filling triangles takes four. ----
-        for (uint64_t todo = __ballot(npx != 0 && !large); todo;) {
+        for (uint64_t todo = zlim_ok ? __ballot(npx != 0 && !large) : 0ull; todo;) {
             const bool cand = (todo >> lane) & 1ull;
             const uint32_t mine = cand ? npx : 0u;
             const uint32_t inc = wave_incl_scan_u32(mine);
@@ -263,9 +266,14 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             wave_lds_sync();
             if (take) {
                 uint4* dst = &s_flat[wv][cidx * 4];
-                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)s.t.C0, (uint32_t)s.t.A1);
-                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)s.t.C1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
-                dst[2] = make_uint4((uint32_t)s.t.C2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
+                // edge functions rebased to the bbox origin: a pair evaluates E(col, row) with no bin coordinates
+                const int32_t ox = (int32_t)(s.t.box & 15u), oy = (int32_t)((s.t.box >> 4) & 15u);
+                const int32_t c0 = s.t.C0 + __mul24(s.t.A0, ox) + __mul24(s.t.B0, oy);
+                const int32_t c1 = s.t.C1 + __mul24(s.t.A1, ox) + __mul24(s.t.B1, oy);
+                const int32_t c2 = s.t.C2 + __mul24(s.t.A2, ox) + __mul24(s.t.B2, oy);
+                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)c0, (uint32_t)s.t.A1);
+                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)c1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
+                dst[2] = make_uint4((uint32_t)c2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
                 // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
                 dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
                 atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
@@ -286,17 +294,18 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                     const uint4* src = &s_flat[wv][tri * 4];
                     const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
                     const uint32_t box = q3.w, k = p - q2.y;
-                    const uint32_t bw = ((box >> 8) & 15u) + 1u, magic = (box >> 12) & 0x1ffffu;
-                    const uint32_t row = (k * magic) >> 16;
-                    const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
-                    const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, lx) + __mul24((int32_t)q0.y, ly);
-                    const int32_t eb1 = (int32_t)q1.y + __mul24((int32_t)q0.w, lx) + __mul24((int32_t)q1.x, ly);
-                    const int32_t eb2 = (int32_t)q2.x + __mul24((int32_t)q1.z, lx) + __mul24((int32_t)q1.w, ly);
+                    const int32_t row = (int32_t)((k * ((box >> 12) & 0x1ffffu)) >> 16);
+                    const int32_t col = (int32_t)k - __mul24(row, (int32_t)((box >> 8) & 15u) + 1);
+                    const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, col) + __mul24((int32_t)q0.y, row);
+                    const int32_t eb1 = (int32_t)q1.y + __mul24((int32_t)q0.w, col) + __mul24((int32_t)q1.x, row);
+                    const int32_t eb2 = (int32_t)q2.x + __mul24((int32_t)q1.z, col) + __mul24((int32_t)q1.w, row);
                     const float b1 = (float)(eb1 + (int32_t)((box >> 29) & 1u)) * __uint_as_float(q3.y);
                     const float b2 = (float)(eb2 + (int32_t)((box >> 30) & 1u)) * __uint_as_float(q3.y);
                     const float z = fmaf(b2, __uint_as_float(q3.x), fmaf(b1, __uint_as_float(q2.w), __uint_as_float(q2.z)));
-                    if ((eb0 | eb1 | eb2) >= 0 && z >= 0.0f && z <= 1.0f && z <= cd)
-                        atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, q3.z));
+                    // 0 <= z <= min(1, clear depth) as ONE unsigned compare of the bit patterns (z is never -0, SPEC.md;
+                    // negative and NaN patterns are above every non-negative bound)
+                    if ((eb0 | eb1 | eb2) >= 0 && __float_as_uint(z) <= zlim)
+                        atomicMax(&s_key[(box & 0xffu) + (uint32_t)(row * MTR_BIN + col)], make_key(z, q3.z));
                 }
             }
         }
