@@ -81,7 +81,7 @@ typedef struct mtr_frame_stats {
     uint64_t bin_entries; /* (triangle, 16x16 bin) pairs */
     uint64_t segments;    /* per-bin ordered runs */
     uint32_t width, height, nbins, ndraws;
-    uint32_t tile_kernel; /* MTR_TILE_ORDERED or MTR_TILE_VISIBILITY: which tile kernel rendered the frame */
+    uint32_t tile_kernel; /* MTR_TILE_ORDERED, MTR_TILE_VISIBILITY or MTR_TILE_MIXED: which tile kernel(s) rendered the frame */
     uint32_t binning;     /* 1 = single-pass bounded queues, 2 = exact two-pass (count, scan, fill) queues */
 } mtr_frame_stats;
 
@@ -99,7 +99,8 @@ int32_t mtr_device_set_profiling(mtr_device *dev, int32_t enable);
 /* tile-kernel choice.  AUTO: the visibility-key kernel when every material of the frame is opaque (debug-id /
  * overlay colours, textures whose alpha is 255 everywhere -- the blend is then a replace), else the ordered
  * kernel.  ORDERED forces the ordered kernel (tests compare both); VISIBILITY is honoured only when eligible. */
-enum { MTR_TILE_AUTO = 0, MTR_TILE_ORDERED = 1, MTR_TILE_VISIBILITY = 2 };
+enum { MTR_TILE_AUTO = 0, MTR_TILE_ORDERED = 1, MTR_TILE_VISIBILITY = 2,
+       MTR_TILE_MIXED = 3 /* reported only: visibility kernel on the bins that hold no translucent triangle, ordered kernel on the rest */ };
 int32_t mtr_device_set_tile_mode(mtr_device *dev, int32_t mode);
 /* triangle -> bin queues.  single_pass != 0 (default): k_geom writes straight into bounded per-bin queues of
  * queue_capacity entries (0 keeps the current bound); a frame that overflows a queue is transparently re-run with the

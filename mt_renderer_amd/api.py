@@ -20,7 +20,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmtr.so")
 
 MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
-TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY = 0, 1, 2
+TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY, TILE_MIXED = 0, 1, 2, 3
 STAGE_NAMES = ("geom", "scan", "fill", "tile")
 
 # every symbol include/mtr.h declares (tests check that the library exports each one)

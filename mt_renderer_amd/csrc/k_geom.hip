@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     const DMat dmat = P.mats[mat];  // wave-uniform
     const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
     // the fragment stage finds the source colour / shader class in the record itself: no dependent material lookup
-    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8);
-    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = dmat.shader | (dmat.blend << 8);
+    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8) | (dmat.translucent << 16);
+    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
     if (n_out >= 1) {
         P.fb.rec_a[base + rank] = r0.a;
         P.fb.rec_hdr[base + rank] = r0.h;

@@ -51,7 +51,7 @@ template <bool TEX>
 __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriC& t, TriX* x,
                                             int4& chi, uint32_t& submask) {
     const RecA a = P.fb.rec_a[r];
-    const uint32_t mshader = a.pad1 & 0xffu, mblend = a.pad1 >> 8;
+    const uint32_t mshader = a.pad1 & 0xffu, mblend = (a.pad1 >> 8) & 0xffu;
     const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
     const long long A2 = (long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]);
     const int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const uint32_t bin = slot * world + P.fb.shard_rank;
     if (slot >= (nbins + world - 1 - P.fb.shard_rank) / world || bin >= nbins) return;
+    if (P.mixed && !P.bin_flag[bin]) return;  // mixed frame: k_tile_vis has rendered this bin (only opaque triangles in it)
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
 
     float dep[4];

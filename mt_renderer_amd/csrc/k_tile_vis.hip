@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
     __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
     __shared__ unsigned long long s_start[VIS_WAVES][64];     // per batch of 64 pairs: which pairs start a triangle
+    __shared__ uint32_t s_trans;                               // mixed frames: the queue holds an order-dependent triangle
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     const uint32_t zlim = __float_as_uint(fminf(cd, 1.0f));
     const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
     for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
+    if (threadIdx.x == 0) s_trans = 0u;
     __syncthreads();
 
     // direct mode: bin b's queue starts at b * qcap whatever its fill, so this wave's first two entry loads are
@@ -188,10 +190,6 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     }
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
     bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
-    if (P.fb.direct && threadIdx.x == 0 && N) {  // queue statistics (direct mode has no scan to count them)
-        atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
-        atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
-    }
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
     // record loads of this wave's next pass and the entry loads of the one after are in flight.  The record of an
@@ -213,6 +211,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         uint32_t ord_nn = 0;
         if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
+        if (P.mixed && valid && (a_cur.pad1 >> 16)) s_trans = 1u;  // benign race: every writer stores 1
         Setup s = {};
         if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);
         const bool large = (s.t.flags & 1u) != 0;
@@ -314,7 +313,18 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         ord_nxt = ord_nn;
     }
     __syncthreads();
-    if (threadIdx.x == 0) bin_queue_done(P.fb, bin);  // every wave has read its queue bounds by now
+    if (P.mixed) {  // an order-dependent triangle in the queue: leave the bin (and its queue) to the ordered kernel
+        const bool tr = s_trans != 0u;
+        if (threadIdx.x == 0) P.bin_flag[bin] = tr ? 1 : 0;
+        if (tr) return;
+    }
+    if (threadIdx.x == 0) {
+        if (P.fb.direct && N) {  // queue statistics (direct mode has no scan to count them)
+            atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
+            atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
+        }
+        bin_queue_done(P.fb, bin);  // every wave has read its queue bounds by now
+    }
 
     // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame;
     //      one pixel per thread, rows of 16 pixels = 64 contiguous bytes ----

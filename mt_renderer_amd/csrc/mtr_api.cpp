@@ -48,6 +48,7 @@ struct Slot {
     unsigned long long* bin_fill = nullptr;
     uint32_t* bin_start = nullptr;
     uint32_t* seg_start = nullptr;
+    uint8_t* bin_flag = nullptr;   // mixed frames: 1 = the bin holds a translucent triangle (ordered kernel's)
     uint32_t bin_cap = 0;
     uint32_t* entries = nullptr;  // submission order of every (triangle, bin) pair
     Seg* segs = nullptr;
@@ -319,7 +320,7 @@ void mtr_device_destroy(mtr_device* d) {
     }
     for (Slot& sl : d->slots) {
         void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
-                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats};
+                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -800,6 +801,8 @@ static int32_t run_frame(mtr_frame* f) {
         if ((rc = dev_grow(d, &sl.bin_fill, &c1, nbins + 1))) return rc;
         if ((rc = dev_grow(d, &sl.bin_start, &c2, nbins + 1))) return rc;
         if ((rc = dev_grow(d, &sl.seg_start, &c3, nbins + 1))) return rc;
+        uint32_t c4 = sl.bin_cap;
+        if ((rc = dev_grow(d, &sl.bin_flag, &c4, nbins + 1))) return rc;
         sl.bin_cap = c0;
         sl.bin_fill_dirty = true;
     }
@@ -846,7 +849,10 @@ static int32_t run_frame(mtr_frame* f) {
                     dm.shader = MTR_SH_CONST; dm.rgba8 = dr.const_rgba8;
                 } else if (tex >= 0 && m->prims[p].has_uv) {  // src/model.rs:212-216
                     dm.shader = MTR_SH_TEXTURED;
-                    if (!m->textures[(size_t)tex]->opaque) f->all_opaque = false;
+                    if (!m->textures[(size_t)tex]->opaque) {
+                        f->all_opaque = false;
+                        dm.translucent = dm.blend;
+                    }
                     dm.tex = m->textures[(size_t)tex]->d_rgba; dm.tw = m->textures[(size_t)tex]->w; dm.th = m->textures[(size_t)tex]->h;
                 } else {
                     dm.shader = MTR_SH_DEBUG; dm.rgba8 = m->debug_rgba8[p];
@@ -922,9 +928,15 @@ static int32_t run_frame(mtr_frame* f) {
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
     bool any_textured = false;
     for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
-    f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : MTR_TILE_ORDERED;
-    if (use_vis) mtr_launch_tile_vis(tp, any_textured, st);
-    else mtr_launch_tile(tp, any_textured, st);
+    // some material translucent, some not: the visibility kernel takes the bins whose queue holds only opaque
+    // triangles (order-free), flags the others, and the ordered kernel renders those in submission order
+    bool any_opaque = false;
+    for (const DMat& dm : mats) any_opaque = any_opaque || !dm.translucent;
+    const bool mixed = !use_vis && d->tile_mode == MTR_TILE_AUTO && any_opaque;
+    tp.bin_flag = sl.bin_flag; tp.mixed = mixed ? 1u : 0u;
+    f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
+    if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
+    if (!use_vis) mtr_launch_tile(tp, any_textured, st);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
     HIPCHK(d, hipEventRecord(f->fb.done, st));
     HIPCHK(d, hipEventRecord(ring, st));

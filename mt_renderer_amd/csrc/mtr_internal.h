@@ -46,7 +46,7 @@ struct DMat {            // one per (draw, [instance,] primitive)
     uint32_t rgba8;      // SH_DEBUG / SH_CONST: the quantised source colour
     uint32_t blend;      // alpha blending on (src/model.rs:243-246) / off (debug overlay)
     uint32_t tw, th;     // texture size
-    uint32_t pad;
+    uint32_t translucent;  // order-dependent: blending on and the texture has a texel with alpha < 255
     const uint8_t* tex;  // decoded RGBA8 texels
 };
 
@@ -59,7 +59,7 @@ struct RecA {            // 48 B: what coverage + depth need
     float z0, z1;
     float z2;
     uint32_t mat;
-    uint32_t pad0, pad1;  // pad0 = material rgba8 (debug / overlay colour), pad1 = shader | blend << 8
+    uint32_t pad0, pad1;  // pad0 = material rgba8 (debug / overlay colour), pad1 = shader | blend << 8 | translucent << 16
 };
 struct RecB {            // 48 B: perspective-correct texcoords (textured primitives only)
     float iw0, iw1, iw2, up0;
@@ -155,6 +155,10 @@ struct TileParams {
     float* depth;
     uint32_t clear_rgba8;
     float clear_depth;
+    // mixed frames (some material translucent): k_tile_vis renders the bins whose queue holds only opaque triangles and
+    // flags the others in bin_flag[]; k_tile then renders the flagged bins in submission order
+    uint8_t* bin_flag;
+    uint32_t mixed;
 };
 
 // launchers (defined in the .hip files, called from mtr_api.cpp)

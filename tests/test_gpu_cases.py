@@ -448,3 +448,30 @@ def test_unordered_binning_mixed_triangle_sizes(gpu_device):
         prims.append(dict(verts=verts, indices=idx, topology=scene.TOPO_STRIP, debug_id=r))
     g = _px(gpu_device, prims, w=512, h=256)
     assert g[2]["tile_kernel"] == 2 and g[2]["binning"] == 1 and g[2]["tris_setup"] > 100, g[2]
+
+
+def test_mixed_frame_uses_both_tile_kernels(gpu_device):
+    """Opaque and translucent materials in one frame: AUTO renders the bins that hold only opaque triangles with the
+    visibility-key kernel and the others with the ordered kernel; the pixels must equal the all-ordered render (and the
+    oracle), including bins where an opaque triangle is submitted AFTER a nearer / farther translucent one."""
+    from mt_renderer_amd import api
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(16, 16, 4), dtype=np.uint8)
+    img[..., 3] = rng.integers(40, 220, size=(16, 16))
+    translucent = scene.TextureData(16, 16, scene.TEX_RGBA8, img.tobytes())
+    opaque = scene.random_bc7_texture(16, 16, 8, opaque_modes_only=True)
+    prims = []
+    for i in range(40):  # opaque: debug-id and opaque-textured quads all over a 160x96 target
+        x0, y0 = rng.uniform(0, 140), rng.uniform(0, 80)
+        sz = rng.uniform(4, 30)
+        if i % 3 == 0:
+            prims.append(_quad(x0, y0, x0 + sz, y0 + sz, float(rng.integers(2, 14)) / 16, tex=1, did=i))
+        else:
+            v = [(x0, y0, .5), (x0, y0 + sz, .5), (x0 + sz, y0 + sz, .5), (x0 + sz, y0, .5)]
+            prims.append(dict(verts=[(a, b, float(rng.integers(2, 14)) / 16) for (a, b, _) in v], indices=[0, 1, 2, 0, 2, 3], debug_id=i))
+    for i in range(12):  # translucent quads confined to the left third, interleaved in submission order
+        x0, y0 = rng.uniform(0, 40), rng.uniform(0, 80)
+        sz = rng.uniform(6, 20)
+        prims.insert(int(rng.integers(0, len(prims))), _quad(x0, y0, x0 + sz, y0 + sz, float(rng.integers(2, 14)) / 16, tex=0))
+    g = _px(gpu_device, prims, w=160, h=96, textures=[translucent, opaque])
+    assert g[2]["tile_kernel"] == api.TILE_MIXED, g[2]

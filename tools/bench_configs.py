@@ -6,6 +6,7 @@ import numpy as np
 from mt_renderer_amd import api, scene
 
 dev = api.Device(0)
+KERNEL_NAMES = {1: 'ordered', 2: 'vis', 3: 'mixed'}
 
 
 def run(name, w, h, md, draw, nframes=30):
@@ -44,7 +45,7 @@ def run(name, w, h, md, draw, nframes=30):
     for fr in frs:
         fr.close()
     print(f"{name}: {dt*1e3:.3f} ms/frame  {st['tris_in']/dt/1e6:.0f} Mtris/s  tris_in={st['tris_in']} setup={st['tris_setup']} "
-          f"entries={st['bin_entries']} kernel={'vis' if st['tile_kernel']==2 else 'ordered'} binning={st['binning']} "
+          f"entries={st['bin_entries']} kernel={KERNEL_NAMES[st['tile_kernel']]} binning={st['binning']} "
           f"stages_ms={ {k: round(v, 4) for k, v in acc.items()} }", flush=True)
     if batch:
         batch.close()
@@ -59,9 +60,10 @@ run("C3  128 inst 1080p", W, H, scene.mesh50k(), dict(vp=scene.to_f32_colmajor(s
 W, H = 3840, 2160
 run("C4  128 inst 4K (1 GPU)", W, H, scene.mesh50k(), dict(vp=scene.to_f32_colmajor(scene.reference_view_proj(W, H)), model_mats=mats, palettes=pals))
 mats, pals = scene.instance_lattice(32, 32)
-for opaque in (True, False):
-    texs = [scene.random_bc7_texture(1024, 1024, seed=200 + i, opaque_modes_only=opaque) for i in range(64)]
+for kind in ("opaque", "translucent", "8 of 64 translucent"):
+    texs = [scene.random_bc7_texture(1024, 1024, seed=200 + i, opaque_modes_only=(kind == "opaque" or (kind != "translucent" and i % 8 != 0)))
+            for i in range(64)]
     md = scene.mesh50k(textured=True, textures=texs)
-    run(f"C5  1024 inst BC7 {'opaque' if opaque else 'translucent'} 4K (1 GPU)", W, H, md,
+    run(f"C5  1024 inst BC7 {kind} 4K (1 GPU)", W, H, md,
         dict(vp=scene.to_f32_colmajor(scene.reference_view_proj(W, H)), model_mats=mats, palettes=pals,
              tex_override=[i // 16 for i in range(1024)]), nframes=10)
