@@ -103,3 +103,4 @@ extern "C" {
     pub fn mtr_model_vertex_stage(model: *mut mtr_model, prim: usize, m: *const f32, out_clip: *mut f32, out_uv: *mut f32) -> i32;
     pub fn mtr_crc32(bytes: *const u8, len: usize, init: u32) -> u32;
 }
+pub mod files;

@@ -222,3 +222,34 @@ def test_rscheduler_tracks_keys_and_eval():
                 mt_files.write_rscheduler(tracks)[:0x60]):
         with pytest.raises(api.MtrError):
             files.SchedulerFile(bad)
+
+
+def test_cpp_mirror_reads_the_same_files(tmp_path):
+    """include/mtr_files.hpp (C++ host mirror): compile a small reader against libmtr.so and run it on synthetic files."""
+    import subprocess
+    md = _model()
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+    sdl = mt_files.write_rscheduler([dict(type=1, name="root"), dict(type=2, name="uModel"),
+                                     dict(type=11, prop=files.PROP_BOOL, name="mDisp", keys=[(0, 0, True), (30, 0, False)])])
+    paths = []
+    for name, data in (("m.mod", rmodel), ("s.mfx", rshader2), ("m.mrl", rmaterial), ("t.tex", rtextures[1]), ("s.sdl", sdl)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+    exe = str(tmp_path / "files_demo")
+    lib_dir = os.path.join(ROOT, "mt_renderer_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "files_demo.cpp"), "-o", exe, "-L", lib_dir, "-lmtr", "-Wl,-rpath," + lib_dir])
+    r = subprocess.run([exe] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    out = r.stdout.splitlines()
+    assert out[0] == "model prims=3 materials=3 boundaries=3"
+    assert out[1].startswith("prim 0 layout=IATest") and "material=mat_0 albedo=1 joint=7" in out[1] and "bound=2" in out[1]
+    assert "material=mat_1 albedo=-1 joint=3" in out[2] and "bound=1" in out[2]
+    assert "albedo=0 joint=11" in out[3]
+    assert out[4] == "texture 8x8 format=19"
+    assert out[-1] == "eval bool@31=0"
+    bad = tmp_path / "bad.mod"
+    bad.write_bytes(rmodel[:100])
+    r = subprocess.run([exe, str(bad)] + paths[1:], capture_output=True, text=True)
+    assert r.returncode == 2 and "rModel" in r.stderr
