@@ -140,7 +140,8 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
 // for frames the visibility-key tile kernel renders (no order kept, no segments)
 template <int MODE>
 #ifndef GEOM_OCC
-#define GEOM_OCC 4  // waves per SIMD the register allocator must leave room for
+#define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
+                    // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
 #endif
 __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
