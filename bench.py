@@ -127,6 +127,17 @@ def main():
             torch.cuda.synchronize()
 
     one_frame(check=True)
+    # Device warm-up, untimed and independent of --warmup: the GPU's power management raises its clocks some 40 ms
+    # after sustained load begins (one ~35 ms stall, then 52 us per frame instead of 58: tools/probe/hiccup.py), so a
+    # short run would time the transition instead of the steady state.  0.3 s of the same frames first.
+    if world > 1:
+        for _ in range(3000 if backend == "nccl" else 20):  # a fixed count: every rank must make the same number of collective calls
+            one_frame()
+    else:
+        t_ramp = time.perf_counter() + 0.3
+        while time.perf_counter() < t_ramp:
+            for _ in range(50):
+                one_frame()
     for _ in range(args.warmup):
         one_frame()
     sync()
