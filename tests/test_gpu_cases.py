@@ -475,3 +475,37 @@ def test_mixed_frame_uses_both_tile_kernels(gpu_device):
         prims.insert(int(rng.integers(0, len(prims))), _quad(x0, y0, x0 + sz, y0 + sz, float(rng.integers(2, 14)) / 16, tex=0))
     g = _px(gpu_device, prims, w=160, h=96, textures=[translucent, opaque])
     assert g[2]["tile_kernel"] == api.TILE_MIXED, g[2]
+
+
+def test_frames_in_flight_keep_their_own_pixels(gpu_device):
+    """Ten frames with different transforms (and two target sizes) are submitted back to back without waiting --
+    they overlap on the library's internal streams, share its slots and recycle colour / depth sets -- then read in
+    a scrambled order; each must equal the oracle's render of ITS transform.  Twice, so the second round runs on
+    recycled framebuffers whose previous frames are still in flight when it starts."""
+    from mt_renderer_amd import api
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=16, cols=24)
+    pal = scene.bone_palette()
+    m = api.Model.new(gpu_device, md)
+    m.set_palette(pal)
+    try:
+        for rnd in range(2):
+            frames, want = [], []
+            for k in range(10):
+                w, h = (240, 136) if k % 3 else (200, 120)
+                T = scene.headline_transform(w, h) @ scene.mat_rot_y(0.3 * k + rnd) @ scene.mat_translate(0.05 * k, -0.02 * k, 0.0)
+                M = scene.to_f32_colmajor(T)
+                fr = api.Frame(gpu_device, w, h)
+                m.render(fr, M)
+                fr.submit()
+                frames.append(fr)
+                want.append((w, h, M))
+            for k in (7, 0, 9, 3, 1, 8, 2, 6, 4, 5):
+                w, h, M = want[k]
+                ref = render_oracle(w, h, [dict(md=md, M=M, palette=pal)])
+                fr = frames[k]
+                fr.wait()
+                assert_same((fr.color(), fr.depth(), fr.stats()), ref, f"frame {k} of round {rnd}")
+            for fr in frames:
+                fr.close()
+    finally:
+        m.close()
