@@ -140,7 +140,8 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
 // for frames the visibility-key tile kernel renders (no order kept, no segments)
 template <int MODE>
 #ifndef GEOM_OCC
-#define GEOM_OCC 4  // waves per SIMD the register allocator must leave room for
+#define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
+                    // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
 #endif
 __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
@@ -208,15 +209,19 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         odd = false;
     }
 
-    PV v1, v2;  // lanes l-1 and l-2
-    v1.X = __shfl_up(me.X, 1); v2.X = __shfl_up(me.X, 2);
-    v1.Y = __shfl_up(me.Y, 1); v2.Y = __shfl_up(me.Y, 2);
-    v1.z = __shfl_up(me.z, 1); v2.z = __shfl_up(me.z, 2);
-    v1.iw = __shfl_up(me.iw, 1); v2.iw = __shfl_up(me.iw, 2);
-    v1.up = __shfl_up(me.up, 1); v2.up = __shfl_up(me.up, 2);
-    v1.vp = __shfl_up(me.vp, 1); v2.vp = __shfl_up(me.vp, 2);
-    v1.flags = __shfl_up(me.flags, 1); v2.flags = __shfl_up(me.flags, 2);
-    const uint32_t vid1 = __shfl_up(vid, 1), vid2 = __shfl_up(vid, 2);
+    // lanes l-1 and l-2 by DPP wave_shr:1 (VALU moves instead of the 14 ds_bpermute behind __shfl_up; same speed in an
+    // A/B run, tools/sweep_ab.sh, but the LDS pipe stays free for the palette reads)
+    PV v1, v2;
+#define MTR_SHR1(x) __builtin_amdgcn_update_dpp((int)(x), (int)(x), 0x138, 0xf, 0xf, false)
+    v1.X = MTR_SHR1(me.X); v2.X = MTR_SHR1(v1.X);
+    v1.Y = MTR_SHR1(me.Y); v2.Y = MTR_SHR1(v1.Y);
+    v1.z = __int_as_float(MTR_SHR1(__float_as_int(me.z))); v2.z = __int_as_float(MTR_SHR1(__float_as_int(v1.z)));
+    v1.iw = __int_as_float(MTR_SHR1(__float_as_int(me.iw))); v2.iw = __int_as_float(MTR_SHR1(__float_as_int(v1.iw)));
+    v1.up = __int_as_float(MTR_SHR1(__float_as_int(me.up))); v2.up = __int_as_float(MTR_SHR1(__float_as_int(v1.up)));
+    v1.vp = __int_as_float(MTR_SHR1(__float_as_int(me.vp))); v2.vp = __int_as_float(MTR_SHR1(__float_as_int(v1.vp)));
+    v1.flags = (uint32_t)MTR_SHR1(me.flags); v2.flags = (uint32_t)MTR_SHR1(v1.flags);
+    const uint32_t vid1 = (uint32_t)MTR_SHR1(vid), vid2 = (uint32_t)MTR_SHR1(vid1);
+#undef MTR_SHR1
 
     // triangle i of a strip = (v_i, v_{i+1}, v_{i+2}) for even i, (v_i, v_{i+2}, v_{i+1}) for odd i
     const PV& ta = v2;
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
 #endif
     const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
     // the fragment stage finds the source colour / shader class in the record itself: no dependent material lookup
-    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8);
-    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = dmat.shader | (dmat.blend << 8);
+    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8) | (dmat.translucent << 16);
+    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
     if (n_out >= 1) {
 #ifndef ABL_NOREC
         P.fb.rec_a[base + rank] = r0.a;

@@ -162,6 +162,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
     __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
     __shared__ unsigned long long s_start[VIS_WAVES][64];     // per batch of 64 pairs: which pairs start a triangle
+    __shared__ uint32_t s_trans;                               // mixed frames: the queue holds an order-dependent triangle
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -170,8 +171,12 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     const uint32_t nbx = P.fb.nbx;
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
     const float cd = P.clear_depth;
+    // fragments pass 0 <= z <= 1 and z <= clear depth (nothing else is in the depth buffer before the resolve)
+    const bool zlim_ok = cd >= 0.0f;
+    const uint32_t zlim = __float_as_uint(fminf(cd, 1.0f));
     const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
     for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
+    if (threadIdx.x == 0) s_trans = 0u;
     __syncthreads();
 
     // direct mode: bin b's queue starts at b * qcap whatever its fill, so this wave's first two entry loads are
@@ -185,10 +190,6 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     }
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
     bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
-    if (P.fb.direct && threadIdx.x == 0 && N) {  // queue statistics (direct mode has no scan to count them)
-        atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
-        atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
-    }
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
     // record loads of this wave's next pass and the entry loads of the one after are in flight.  The record of an
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         uint32_t ord_nn = 0;
         if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
+        if (P.mixed && valid && (a_cur.pad1 >> 16)) s_trans = 1u;  // benign race: every writer stores 1
         Setup s = {};
 #ifdef ABL_T_NOSETUP
         if (valid && a_cur.X0 == 0x7ffffff0) s_key[0] = 1;
@@ -218,40 +220,12 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 #endif
         const bool large = (s.t.flags & 1u) != 0;
         const uint32_t npx = (uint32_t)s.npx;
-        // flat class: i32 edge functions and at most 64 pixels of the bin's 256, so a pass holds <= 4096 pairs
-        const bool flat = npx != 0 && !large && npx <= 64u;
-        const uint64_t fm = __ballot(flat);
-        uint32_t total = 0;
-#ifdef ABL_T_NOSTAGE
-        if (fm == 0x7ffffff0) {
-#else
-        if (fm) {
-#endif
-            // ---- stage the flat triangles, compacted, with their pair prefix; mark where each one starts ----
-            const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-            const uint32_t mine = flat ? npx : 0u;
-            const uint32_t inc = wave_incl_scan_u32(mine);
-            total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            const uint32_t pre = inc - mine;
-            s_start[wv][lane] = 0ull;
-            wave_lds_sync();
-            if (flat) {
-                uint4* dst = &s_flat[wv][cidx * 4];
-                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)s.t.C0, (uint32_t)s.t.A1);
-                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)s.t.C1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
-                dst[2] = make_uint4((uint32_t)s.t.C2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
-                // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
-                dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
-                atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
-            }
-            wave_lds_sync();
-        }
-
-        // ---- lane = pixel of the bbox: the big triangles, broadcast one at a time with v_readlane ----
+        // ---- lane = pixel of the bbox: triangles that need 64-bit edge functions (more than 64 px across: rare),
+        //      broadcast one at a time with v_readlane ----
 #ifdef ABL_T_NOCOOP
-        for (uint64_t mb = __ballot(npx == 0x7ffffff0); mb; mb &= mb - 1) {
+        for (uint64_t mb = 0; mb; mb &= mb - 1) {
 #else
-        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {
+        for (uint64_t mb = __ballot(npx != 0 && large); mb; mb &= mb - 1) {
 #endif
             const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__ffsll((long long)mb) - 1);
 #define RL(x) __builtin_amdgcn_readlane((int)(x), t)
@@ -266,39 +240,56 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             for (uint32_t k = lane; k < tn; k += 64) {
                 const uint32_t row = (k * magic) >> 16;
                 const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
-                bool inside;
-                float e1f, e2f;
-                if (!(flags & 1u)) {
-                    const int32_t eb0 = C0 + __mul24(A0, lx) + __mul24(B0, ly);
-                    const int32_t eb1 = C1 + __mul24(A1, lx) + __mul24(B1, ly);
-                    const int32_t eb2 = C2 + __mul24(A2, lx) + __mul24(B2, ly);
-                    inside = (eb0 | eb1 | eb2) >= 0;
-                    e1f = (float)(eb1 + (int32_t)((flags >> 5) & 1u));
-                    e2f = (float)(eb2 + (int32_t)((flags >> 6) & 1u));
-                } else {
-                    const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
-                    const long long c0 = ((long long)H0 << 32) | (unsigned long long)(uint32_t)C0;
-                    const long long c1 = ((long long)H1 << 32) | (unsigned long long)(uint32_t)C1;
-                    const long long c2 = ((long long)H2 << 32) | (unsigned long long)(uint32_t)C2;
-                    const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
-                    const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
-                    const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
-                    inside = (eb0 | eb1 | eb2) >= 0;
-                    e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
-                    e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
-                }
+                const long long Xp = (long long)lx * 256, Yp = (long long)ly * 256;
+                const long long c0 = ((long long)H0 << 32) | (unsigned long long)(uint32_t)C0;
+                const long long c1 = ((long long)H1 << 32) | (unsigned long long)(uint32_t)C1;
+                const long long c2 = ((long long)H2 << 32) | (unsigned long long)(uint32_t)C2;
+                const long long eb0 = c0 + (long long)A0 * Xp + (long long)B0 * Yp;
+                const long long eb1 = c1 + (long long)A1 * Xp + (long long)B1 * Yp;
+                const long long eb2 = c2 + (long long)A2 * Xp + (long long)B2 * Yp;
+                const bool inside = (eb0 | eb1 | eb2) >= 0;
+                const float e1f = (float)(eb1 + (long long)((flags >> 5) & 1u));
+                const float e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
                 const float b1 = e1f * rcpA, b2 = e2f * rcpA;
                 const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
                 if (inside && z >= 0.0f && z <= 1.0f && z <= cd) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
             }
         }
 
-        // ---- lane = (triangle, pixel) pair of the flat class, 64 pairs per step ----
+        // ---- lane = (triangle, pixel) pair, 64 pairs per step, for every i32-class triangle.  A round stages a
+        //      prefix of the remaining triangles holding <= 4096 pairs (64 start masks, one per lane); one round
+        //      is the rule, a pass of 64 bin-filling triangles takes four. ----
 #ifdef ABL_T_NOFLAT
-        if (total == 0x7ffffff0) {
+        for (uint64_t todo = 0; todo;) {
 #else
-        if (total) {
+        for (uint64_t todo = zlim_ok ? __ballot(npx != 0 && !large) : 0ull; todo;) {
 #endif
+            const bool cand = (todo >> lane) & 1ull;
+            const uint32_t mine = cand ? npx : 0u;
+            const uint32_t inc = wave_incl_scan_u32(mine);
+            const bool take = cand && inc <= 4096u;  // npx <= 256: the first candidate always fits
+            const uint64_t tm = __ballot(take);
+            todo &= ~tm;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63 - __builtin_clzll(tm));
+            const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u));
+            const uint32_t pre = inc - mine;
+            s_start[wv][lane] = 0ull;
+            wave_lds_sync();
+            if (take) {
+                uint4* dst = &s_flat[wv][cidx * 4];
+                // edge functions rebased to the bbox origin: a pair evaluates E(col, row) with no bin coordinates
+                const int32_t ox = (int32_t)(s.t.box & 15u), oy = (int32_t)((s.t.box >> 4) & 15u);
+                const int32_t c0 = s.t.C0 + __mul24(s.t.A0, ox) + __mul24(s.t.B0, oy);
+                const int32_t c1 = s.t.C1 + __mul24(s.t.A1, ox) + __mul24(s.t.B1, oy);
+                const int32_t c2 = s.t.C2 + __mul24(s.t.A2, ox) + __mul24(s.t.B2, oy);
+                dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)c0, (uint32_t)s.t.A1);
+                dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)c1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
+                dst[2] = make_uint4((uint32_t)c2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
+                // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
+                dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
+                atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
+            }
+            wave_lds_sync();
             const unsigned long long my_start = s_start[wv][lane];
             const uint32_t nb = (total + 63u) >> 6;
             uint32_t base = 0;
@@ -314,17 +305,18 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                     const uint4* src = &s_flat[wv][tri * 4];
                     const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
                     const uint32_t box = q3.w, k = p - q2.y;
-                    const uint32_t bw = ((box >> 8) & 15u) + 1u, magic = (box >> 12) & 0x1ffffu;
-                    const uint32_t row = (k * magic) >> 16;
-                    const int32_t lx = (int32_t)((box & 15u) + (k - row * bw)), ly = (int32_t)(((box >> 4) & 15u) + row);
-                    const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, lx) + __mul24((int32_t)q0.y, ly);
-                    const int32_t eb1 = (int32_t)q1.y + __mul24((int32_t)q0.w, lx) + __mul24((int32_t)q1.x, ly);
-                    const int32_t eb2 = (int32_t)q2.x + __mul24((int32_t)q1.z, lx) + __mul24((int32_t)q1.w, ly);
+                    const int32_t row = (int32_t)((k * ((box >> 12) & 0x1ffffu)) >> 16);
+                    const int32_t col = (int32_t)k - __mul24(row, (int32_t)((box >> 8) & 15u) + 1);
+                    const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, col) + __mul24((int32_t)q0.y, row);
+                    const int32_t eb1 = (int32_t)q1.y + __mul24((int32_t)q0.w, col) + __mul24((int32_t)q1.x, row);
+                    const int32_t eb2 = (int32_t)q2.x + __mul24((int32_t)q1.z, col) + __mul24((int32_t)q1.w, row);
                     const float b1 = (float)(eb1 + (int32_t)((box >> 29) & 1u)) * __uint_as_float(q3.y);
                     const float b2 = (float)(eb2 + (int32_t)((box >> 30) & 1u)) * __uint_as_float(q3.y);
                     const float z = fmaf(b2, __uint_as_float(q3.x), fmaf(b1, __uint_as_float(q2.w), __uint_as_float(q2.z)));
-                    if ((eb0 | eb1 | eb2) >= 0 && z >= 0.0f && z <= 1.0f && z <= cd)
-                        atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, q3.z));
+                    // 0 <= z <= min(1, clear depth) as ONE unsigned compare of the bit patterns (z is never -0, SPEC.md;
+                    // negative and NaN patterns are above every non-negative bound)
+                    if ((eb0 | eb1 | eb2) >= 0 && __float_as_uint(z) <= zlim)
+                        atomicMax(&s_key[(box & 0xffu) + (uint32_t)(row * MTR_BIN + col)], make_key(z, q3.z));
                 }
             }
         }
@@ -333,7 +325,18 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         ord_nxt = ord_nn;
     }
     __syncthreads();
-    if (threadIdx.x == 0) bin_queue_done(P.fb, bin);  // every wave has read its queue bounds by now
+    if (P.mixed) {  // an order-dependent triangle in the queue: leave the bin (and its queue) to the ordered kernel
+        const bool tr = s_trans != 0u;
+        if (threadIdx.x == 0) P.bin_flag[bin] = tr ? 1 : 0;
+        if (tr) return;
+    }
+    if (threadIdx.x == 0) {
+        if (P.fb.direct && N) {  // queue statistics (direct mode has no scan to count them)
+            atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], N);
+            atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], n_seg);
+        }
+        bin_queue_done(P.fb, bin);  // every wave has read its queue bounds by now
+    }
 
     // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame;
     //      one pixel per thread, rows of 16 pixels = 64 contiguous bytes ----

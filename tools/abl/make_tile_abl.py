@@ -14,12 +14,12 @@ def sub(old, new):
 sub("        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);",
     "#ifdef ABL_T_NOSETUP\n        if (valid && a_cur.X0 == 0x7ffffff0) s_key[0] = 1;\n#else\n"
     "        if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);\n#endif")
-sub("        if (total) {\n            const unsigned long long my_start",
-    "#ifdef ABL_T_NOFLAT\n        if (total == 0x7ffffff0) {\n#else\n        if (total) {\n#endif\n            const unsigned long long my_start")
-sub("        if (fm) {\n", "#ifdef ABL_T_NOSTAGE\n        if (fm == 0x7ffffff0) {\n#else\n        if (fm) {\n#endif\n")
-sub("        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {",
-    "#ifdef ABL_T_NOCOOP\n        for (uint64_t mb = __ballot(npx == 0x7ffffff0); mb; mb &= mb - 1) {\n#else\n"
-    "        for (uint64_t mb = __ballot(npx != 0 && !flat); mb; mb &= mb - 1) {\n#endif")
+sub("        for (uint64_t todo = zlim_ok ? __ballot(npx != 0 && !large) : 0ull; todo;) {",
+    "#ifdef ABL_T_NOFLAT\n        for (uint64_t todo = 0; todo;) {\n#else\n"
+    "        for (uint64_t todo = zlim_ok ? __ballot(npx != 0 && !large) : 0ull; todo;) {\n#endif")
+sub("        for (uint64_t mb = __ballot(npx != 0 && large); mb; mb &= mb - 1) {",
+    "#ifdef ABL_T_NOCOOP\n        for (uint64_t mb = 0; mb; mb &= mb - 1) {\n#else\n"
+    "        for (uint64_t mb = __ballot(npx != 0 && large); mb; mb &= mb - 1) {\n#endif")
 sub("            const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];",
     "#ifdef ABL_T_NOWINNER\n            const uint4 tail = {r, r, r, 0u};\n#else\n"
     "            const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];\n#endif")
