@@ -13,7 +13,9 @@
  *   rScheduler(.sdl)  src/rscheduler.rs:36-84 (structs), :88-216 (SchedulerFile::new), size :222
  *
  * All multi-byte fields are little-endian and unaligned ("repr(C, packed)" in the reference).  "View" structs
- * point INTO the caller's buffer, which must outlive them; handles own their memory.
+ * point INTO the caller's buffer, which must outlive them; their typed pointers (primitives, lmats, imats,
+ * index_buf) sit wherever the file put the data and may be UNALIGNED: copy with memcpy before dereferencing on a
+ * strict-alignment target (the library itself only ever memcpy's them).  Handles own their memory.
  */
 #ifndef MTR_FILES_H
 #define MTR_FILES_H

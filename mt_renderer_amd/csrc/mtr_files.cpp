@@ -491,7 +491,11 @@ int32_t mtr_rmaterial_parse(const void* data, size_t len, const mtr_rshader2* sh
                     return ferr(MTR_E_INVALID, "rMaterial: state %u of material %u names an unknown object", k, i);
                 }
             } else if (type == 3 && st.sh_value != 0) {  // TEXTURE: 1-based index into the texture list
-                if (st.sh_value - 1 >= m->textures.size()) { delete m; return ferr(MTR_E_INVALID, "rMaterial: state %u of material %u names texture %llu of %zu", k, i, (unsigned long long)st.sh_value, m->textures.size()); }
+                if (st.sh_value - 1 >= m->textures.size()) {
+                    const size_t have = m->textures.size();
+                    delete m;
+                    return ferr(MTR_E_INVALID, "rMaterial: state %u of material %u names texture %llu of %zu", k, i, (unsigned long long)st.sh_value, have);
+                }
                 if (sh->objects[(size_t)obj].name == "tAlbedoMap") info.albedo_texture = (int32_t)(st.sh_value - 1);
             }
         }

@@ -231,7 +231,7 @@ class Shader2File:
         for i in range(lib.mtr_rshader2_num_objects(self.h)):
             name, ot, nh = C.c_char_p(), C.c_uint32(), C.c_uint32()
             _check(lib.mtr_rshader2_object(self.h, i, C.byref(name), C.byref(ot), C.byref(nh)))
-            out.append(dict(name=name.value.decode(), obj_type=ot.value, name_hash=nh.value))
+            out.append(dict(name=name.value.decode(errors="replace"), obj_type=ot.value, name_hash=nh.value))
         return out
 
     def get_object_by_handle(self, handle: int) -> Optional[int]:
@@ -243,7 +243,7 @@ class Shader2File:
         lay = api._Layout()
         raw = (_RawElement * 64)()
         _check(lib.mtr_rshader2_input_layout(self.h, i, C.byref(stride), C.byref(lay), raw, 64, C.byref(n)))
-        els = [dict(name=raw[e].name.decode(), sindex=raw[e].sindex, format=raw[e].format, count=raw[e].count,
+        els = [dict(name=raw[e].name.decode(errors="replace"), sindex=raw[e].sindex, format=raw[e].format, count=raw[e].count,
                     start=raw[e].start, offset=raw[e].offset, instance=raw[e].instance) for e in range(min(n.value, 64))]
         bound = [(lay.elements[e].semantic, lay.elements[e].format, lay.elements[e].count, lay.elements[e].offset)
                  for e in range(lay.num_elements)]
@@ -265,7 +265,7 @@ class MaterialFile:
     __del__ = close
 
     def textures(self) -> List[str]:
-        return [lib.mtr_rmaterial_texture_path(self.h, i).decode() for i in range(lib.mtr_rmaterial_num_textures(self.h))]
+        return [lib.mtr_rmaterial_texture_path(self.h, i).decode(errors="replace") for i in range(lib.mtr_rmaterial_num_textures(self.h))]
 
     def materials(self) -> List[dict]:
         out = []
@@ -308,7 +308,7 @@ class SchedulerFile:
     def key(self, track: int, k: int) -> dict:
         fr, mode, val, res = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_char_p()
         _check(lib.mtr_rscheduler_key(self.h, track, k, C.byref(fr), C.byref(mode), C.byref(val), C.byref(res)))
-        return dict(frame=fr.value, mode=mode.value, value_bits=val.value, resource=None if res.value is None else res.value.decode())
+        return dict(frame=fr.value, mode=mode.value, value_bits=val.value, resource=None if res.value is None else res.value.decode(errors="replace"))
 
     def eval(self, track: int, frame: int) -> int:
         val = C.c_uint64()

@@ -253,3 +253,99 @@ def test_cpp_mirror_reads_the_same_files(tmp_path):
     bad.write_bytes(rmodel[:100])
     r = subprocess.run([exe, str(bad)] + paths[1:], capture_output=True, text=True)
     assert r.returncode == 2 and "rModel" in r.stderr
+
+
+def test_parsers_survive_mutated_files():
+    """Robustness: random byte flips, field overwrites with huge values and truncations of valid files must end in a
+    normal return or an MtrError -- never a crash (every offset and count read from a file is bounds-checked).  A
+    parse that succeeds is also walked through its accessors."""
+    md = _model()
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+    sdl = mt_files.write_rscheduler([dict(type=1, name="root"), dict(type=11, prop=files.PROP_BOOL, name="b", keys=[(0, 0, True), (9, 1, False)]),
+                                     dict(type=9, prop=files.PROP_F32, name="f", keys=[(0, 0, 1.0)]),
+                                     dict(type=13, prop=2, name="r", keys=[(0, 0, (5, "a\\b")), (1, 0, None)])])
+    sh_ok = files.Shader2File(rshader2)
+    rng = np.random.default_rng(1234)
+
+    def mutate(b: bytes) -> bytes:
+        a = bytearray(b)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                a[int(rng.integers(0, len(a)))] = int(rng.integers(0, 256))
+        elif kind == 1:  # a 32/64-bit field becomes huge
+            off = int(rng.integers(0, max(1, min(len(a), 0x100) - 8))) & ~3
+            big = [0xFFFFFFFFFFFFFFFF, 0x7FFFFFFF, len(a), len(a) - 1, 0x80000000][int(rng.integers(0, 5))]
+            a[off:off + 8] = struct.pack("<Q", big)
+        elif kind == 2:
+            a = a[:int(rng.integers(0, len(a)))]
+        else:
+            off = int(rng.integers(0, len(a)))
+            a[off:off + 4] = bytes(4)
+        return bytes(a)
+
+    def walk_model(b):
+        mf = files.ModelFile(b)
+        mf.material_names(); mf.vertex_buf(); mf.index_buf(); mf.joint_table()
+        for p in range(mf.v.primitive_num):
+            mf.boundary_joint(mf.primitive_field(p, files.PRIM_BOUNDARY_NUM))
+
+    def walk_shader(b):
+        sh = files.Shader2File(b)
+        for i, o in enumerate(sh.objects()):
+            if o["obj_type"] == 9:
+                sh.input_layout(i)
+
+    def walk_material(b):
+        m = files.MaterialFile(b, sh_ok)
+        m.textures(); m.materials()
+
+    def walk_sdl(b):
+        s = files.SchedulerFile(b)
+        for i, t in enumerate(s.tracks()):
+            for k in range(t["key_num"]):
+                try:
+                    s.key(i, k)
+                except api.MtrError:
+                    pass
+
+    outcomes = {"ok": 0, "err": 0}
+    for good, walk in ((rmodel, walk_model), (rshader2, walk_shader), (rmaterial, walk_material),
+                       (rtextures[0], lambda b: files.TextureFile(b).data()), (sdl, walk_sdl)):
+        walk(good)
+        for _ in range(400):
+            try:
+                walk(mutate(good))
+                outcomes["ok"] += 1
+            except api.MtrError:
+                outcomes["err"] += 1
+    assert outcomes["err"] > 300 and outcomes["ok"] > 100, outcomes
+
+
+def test_parsers_under_address_sanitizer(tmp_path):
+    """The same kind of mutations, 30 000 of them, against an AddressSanitizer + UBSan build of csrc/mtr_files.cpp
+    (host-only build with stand-ins for the device entry points; sanitizers cannot run on the GPU box)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    md = _model()
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+    joints = [(i, max(i - 1, 0), (0.1 * i, 0.0, 1.0)) for i in range(4)]
+    rmodel_j = mt_files.write_rmodel(md, [mt_files.handle_of("IATest0")] * 3, ["mat_0", "mat_1", "mat_2"], [0, 1, 2], joints=joints,
+                                     lmats=np.zeros((4, 16), np.float32), imats=np.ones((4, 16), np.float32))
+    sdl = mt_files.write_rscheduler([dict(type=1, name="root"), dict(type=11, prop=files.PROP_BOOL, name="b", keys=[(0, 0, True), (9, 1, False)]),
+                                     dict(type=6, prop=files.PROP_U32, name="i", keys=[(0, 0, 3)]),
+                                     dict(type=13, prop=2, name="r", keys=[(0, 0, (5, "a\\b")), (1, 0, None)])])
+    paths = []
+    for name, data in (("m.mod", rmodel_j), ("s.mfx", rshader2), ("m.mrl", rmaterial), ("t.tex", rtextures[0]), ("s.sdl", sdl)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        paths.append(str(p))
+    exe = str(tmp_path / "files_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "files_fuzz.cpp"), "-o", exe])
+    r = subprocess.run([exe, "30000"] + paths, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    ok, err = [int(t.split("=")[1]) for t in r.stdout.split()]
+    assert ok > 1000 and err > 5000, r.stdout
