@@ -501,7 +501,8 @@ int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_le
         m->debug_rgba8[p] = pack_rgba8(c);
     }
     m->parts_disp.assign(nprims, 1);  // src/model.rs:270
-    m->indices.assign(index_buf, index_buf + index_num);
+    m->indices.resize(index_num);  // the caller's pointer may be an unaligned view into a file image: bytes only
+    if (index_num) memcpy(m->indices.data(), index_buf, index_num * sizeof(uint16_t));
     m->run.resize(index_num);
     {
         // runs restart at every primitive's first index so a chunk never looks outside its primitive
@@ -510,7 +511,7 @@ int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_le
         uint32_t r = 0;
         for (size_t i = 0; i < index_num; i++) {
             if (is_first[i]) r = 0;
-            r = index_buf[i] == 0xFFFF ? 0 : r + 1;
+            r = m->indices[i] == 0xFFFF ? 0 : r + 1;
             m->run[i] = r;
         }
     }
@@ -866,7 +867,8 @@ static int32_t run_frame(mtr_frame* f) {
         sl.mats_uploaded.clear();
     }
     // the material table is tiny; the copy is ordered on the stream before the kernels that read it
-    if (mats.size() != sl.mats_uploaded.size() || memcmp(mats.data(), sl.mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0) {
+    if (mats.size() != sl.mats_uploaded.size() ||
+        (!mats.empty() && memcmp(mats.data(), sl.mats_uploaded.data(), mats.size() * sizeof(DMat)) != 0)) {
         HIPCHK(d, hipMemcpyAsync(sl.mats, mats.data(), mats.size() * sizeof(DMat), hipMemcpyHostToDevice, sl.stream));
         sl.mats_uploaded = mats;
     }
