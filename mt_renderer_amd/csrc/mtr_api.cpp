@@ -774,8 +774,9 @@ static int32_t run_frame(mtr_frame* f) {
         nmats += (uint64_t)m->prims.size() * (dr.tex_override.empty() ? 1 : dr.ninst);
         tris_in += m->ntris_visible * dr.ninst;
     }
-    // a (triangle, bin) entry is the 32-bit submission order chunk * 128 + slot: 2^25 chunks (2 G triangles) per frame
-    if (total_chunks >= (1ull << 25)) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
+    // a (triangle, bin) entry is the 32-bit submission order chunk * 128 + slot, and the visibility key stores order + 1:
+    // fewer than 2^25 - 1 chunks (2 G triangles) per frame
+    if (total_chunks >= (1ull << 25) - 1) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
     // this frame's slot: the other slots may still be feeding earlier frames' tile kernels
     hipEvent_t& ring = d->inflight[d->frame_counter % d->max_inflight];
     if (ring) HIPCHK(d, hipEventSynchronize(ring));  // frame (i - max_inflight) has left the GPU
