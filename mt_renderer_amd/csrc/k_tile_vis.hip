@@ -175,10 +175,6 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     const bool zlim_ok = cd >= 0.0f;
     const uint32_t zlim = __float_as_uint(fminf(cd, 1.0f));
     const int32_t vw = (int32_t)P.fb.W - binx0, vh = (int32_t)P.fb.H - biny0;  // viewport edge in bin coordinates
-    for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
-    if (threadIdx.x == 0) s_trans = 0u;
-    __syncthreads();
-
     // direct mode: bin b's queue starts at b * qcap whatever its fill, so this wave's first two entry loads are
     // issued together with the fill-count load instead of after it (one dependent round trip less per bin)
     const uint32_t stride = 64 * VIS_WAVES, first = wv * 64;
@@ -189,7 +185,23 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         if (first + stride + lane < P.fb.qcap) spec1 = P.fb.entries[qb + first + stride + lane];
     }
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
-    bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);
+    bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);  // the same word for every thread of the workgroup
+    if (N == 0) {
+        // an empty bin (a third of the headline frame): clear colour / depth and leave, no LDS, no barrier
+        for (uint32_t pidx = threadIdx.x; pidx < MTR_BIN * MTR_BIN; pidx += 64 * VIS_WAVES) {
+            const int32_t lx = (int32_t)(pidx & (MTR_BIN - 1)), ly = (int32_t)(pidx >> MTR_BIN_SHIFT);
+            if (lx >= vw || ly >= vh) continue;
+            const size_t pi = (size_t)(biny0 + ly) * P.fb.W + (size_t)(binx0 + lx);
+            reinterpret_cast<uint32_t*>(P.color)[pi] = P.clear_rgba8;
+            P.depth[pi] = cd;
+        }
+        if (P.mixed && threadIdx.x == 0) P.bin_flag[bin] = 0;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
+    if (threadIdx.x == 0) s_trans = 0u;
+    __syncthreads();
+
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
     // two-deep software pipeline over the dependent loads entries[] -> rec_a[]: while pass k is rasterised the
     // record loads of this wave's next pass and the entry loads of the one after are in flight.  The record of an
