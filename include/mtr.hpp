@@ -28,6 +28,11 @@ class Device {
     Device& operator=(const Device&) = delete;
     ~Device() { mtr_device_destroy(h_); }
     mtr_device* handle() const { return h_; }
+    void set_tile_mode(int32_t mode) const { check(mtr_device_set_tile_mode(h_, mode)); }  // MTR_TILE_AUTO / ORDERED / VISIBILITY
+    void set_binning(bool single_pass, uint32_t queue_capacity = 0) const { check(mtr_device_set_binning(h_, single_pass ? 1 : 0, queue_capacity)); }
+    void unpack_color_shards(const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h, void* dst_dev) const {
+        check(mtr_device_unpack_color_shards(h_, gathered_dev, world, w, h, dst_dev));
+    }
     void check(int32_t rc) const {
         if (rc) throw Error(rc, mtr_last_error(h_));
     }
@@ -93,6 +98,14 @@ class Frame {
     Frame(const Frame&) = delete;
     ~Frame() { mtr_frame_destroy(h_); }
     void end() { dev_.check(mtr_frame_end(h_)); }  // queue.submit, src/renderer_app_manager.rs:185
+    // end() in two halves, so a host can keep several frames in flight (the library overlaps them on its own streams)
+    void submit() { dev_.check(mtr_frame_submit(h_)); }
+    void wait() { dev_.check(mtr_frame_wait(h_)); }
+    // multi-GPU: render only the bins with (bin % world) == rank, then pack them for the all-gather
+    void set_shard(uint32_t rank, uint32_t world) { dev_.check(mtr_frame_set_shard(h_, rank, world)); }
+    void pack_color_shard(void* dst_dev, size_t dst_bytes) { dev_.check(mtr_frame_pack_color_shard(h_, dst_dev, dst_bytes)); }
+    void* color_devptr() const { return mtr_frame_color_devptr(h_); }
+    void* depth_devptr() const { return mtr_frame_depth_devptr(h_); }
     void read_color(void* rgba8, size_t len) { dev_.check(mtr_frame_read_color(h_, rgba8, len)); }
     void read_depth(float* d, size_t count) { dev_.check(mtr_frame_read_depth(h_, d, count)); }
     mtr_frame_stats stats() {

@@ -29,6 +29,11 @@ impl Device {
         check(ptr::null(), unsafe { sys::mtr_device_create(hip_device, &mut h) })?;
         Ok(Device(h))
     }
+    /// MTR_TILE_AUTO (0) / ORDERED (1) / VISIBILITY (2)
+    pub fn set_tile_mode(&self, mode: i32) -> Result<()> { check(self.0, unsafe { sys::mtr_device_set_tile_mode(self.0, mode) }) }
+    pub fn set_binning(&self, single_pass: bool, queue_capacity: u32) -> Result<()> {
+        check(self.0, unsafe { sys::mtr_device_set_binning(self.0, single_pass as i32, queue_capacity) })
+    }
 }
 impl Drop for Device { fn drop(&mut self) { unsafe { sys::mtr_device_destroy(self.0) } } }
 
@@ -88,6 +93,11 @@ impl<'d> Frame<'d> {
     }
     /// queue.submit + wait -- src/renderer_app_manager.rs:185
     pub fn end(&mut self) -> Result<()> { check(self.dev.0, unsafe { sys::mtr_frame_end(self.h) }) }
+    /// `end` in two halves: keep several frames in flight (the library overlaps them on its own streams)
+    pub fn submit(&mut self) -> Result<()> { check(self.dev.0, unsafe { sys::mtr_frame_submit(self.h) }) }
+    pub fn wait(&mut self) -> Result<()> { check(self.dev.0, unsafe { sys::mtr_frame_wait(self.h) }) }
+    /// multi-GPU: render only the bins with `bin % world == rank`
+    pub fn set_shard(&mut self, rank: u32, world: u32) -> Result<()> { check(self.dev.0, unsafe { sys::mtr_frame_set_shard(self.h, rank, world) }) }
     pub fn read_color(&mut self, out: &mut [u8]) -> Result<()> {
         check(self.dev.0, unsafe { sys::mtr_frame_read_color(self.h, out.as_mut_ptr().cast(), out.len()) })
     }
