@@ -1,5 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT/mt_renderer_amd/csrc
+make -s k_geom.o  # the other kernel: the stock build (an earlier ablation may have left a variant behind)
 python ../../tools/abl/make_tile_abl.py
 cp ../../tools/abl/k_tile_vis_abl.hip ./k_tile_vis_abl.hip
 for v in "ABL_NONE" "ABL_T_NOFLAT" "ABL_T_NOCOOP" "ABL_T_NOSETUP" "ABL_T_NOWINNER"; do

@@ -97,3 +97,9 @@ print("lane=triangle (now)        : %.1f M units" % (base / 1e6))
 print("lane=triangle trimmed loop : %.1f M" % (sim("lane", 30, (16, 32, 64, 128, 256)) / 1e6))
 for G in (2, 4, 8):
     print("G=%d column walk            : %.1f M" % (G, sim(G, 32, (8, 16, 32, 64, 128, 256)) / 1e6))
+
+# ---- per-bin totals: what one workgroup of the visibility kernel has to walk ----
+pairs = np.bincount(e[:, 0], weights=e[:, 1], minlength=8160)
+nz = pairs[pairs > 0]
+print("pairs per non-empty bin: mean %.0f  p50 %.0f  p90 %.0f  p99 %.0f  max %.0f  (sum %.0f)" % (nz.mean(), *np.percentile(nz, [50, 90, 99]), nz.max(), nz.sum()))
+print("bins with more than 4x the mean: %d; their share of all pairs: %.1f%%" % ((nz > 4 * nz.mean()).sum(), 100 * nz[nz > 4 * nz.mean()].sum() / nz.sum()))
