@@ -19,6 +19,7 @@
 namespace mtr {
 
 #define TRI_PASS 64
+#define FRAG_K 8u  // fragment-list path: triangle numbers kept per pixel and pass
 
 // per-triangle set-up in LDS.  TriC (64 B) is read by every (triangle, sub-tile) visit as four
 // broadcast ds_read_b128; TriX (64 B) only by textured triangles.
@@ -33,7 +34,7 @@ struct TriC {
     float z0, dz1;
     float dz2, rcpA;
     uint32_t rgba8;  // quantised source colour of the debug / constant shaders
-    uint32_t pad;
+    uint32_t pad;    // bbox inside the bin (fragment-list path), see setup_entry
 };
 struct TriX {
     float iw0, diw1, diw2, up0;
@@ -82,7 +83,6 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
     t.z0 = a.z0; t.dz1 = a.z1 - a.z0; t.dz2 = a.z2 - a.z0;
     t.rcpA = 1.0f / (float)A2;
     t.rgba8 = a.pad0;
-    t.pad = 0;
     chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
     // sub-tiles (8x8 px) of this bin touched by the pixel-centre bbox: bit = sy*2 + sx
     int32_t px0 = ((xmin + 127) >> 8) - binx0, px1 = ((xmax - 128) >> 8) - binx0;
@@ -94,6 +94,11 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
         if (py1 >= 8) sm |= colbits << 2;
     }
     submask = sm;
+    // bbox clipped to the bin, for the fragment-list path: px0 | py0 << 4 | (w-1) << 8 | (h-1) << 12 | non-empty << 16
+    {
+        const int32_t cx0 = max(px0, 0), cx1 = min(px1, MTR_BIN - 1), cy0 = max(py0, 0), cy1 = min(py1, MTR_BIN - 1);
+        t.pad = (cx0 <= cx1 && cy0 <= cy1) ? ((uint32_t)cx0 | ((uint32_t)cy0 << 4) | ((uint32_t)(cx1 - cx0) << 8) | ((uint32_t)(cy1 - cy0) << 12) | (1u << 16)) : 0u;
+    }
     if (TEX && mshader == MTR_SH_TEXTURED) {
         const DMat mat = P.mats[a.mat];
         const RecB b = P.fb.rec_b[r];
@@ -112,6 +117,12 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     __shared__ uint32_t s_mask[TRI_PASS];
     __shared__ uint32_t s_off[64], s_pre[65];
     __shared__ Seg s_seg[64];
+    // fragment-list path: per pixel a count and up to FRAG_K triangle numbers of the current pass
+    __shared__ uint32_t s_cnt[MTR_BIN * MTR_BIN];
+    __shared__ uint8_t s_frag[MTR_BIN * MTR_BIN * FRAG_K];
+    __shared__ unsigned long long s_start[32];  // <= 2048 pairs per pass: 32 batches of 64
+    __shared__ uint32_t s_pm[TRI_PASS];         // pair prefix | magic(bbox width) << 12
+    __shared__ uint8_t s_tmap[TRI_PASS];        // compacted index -> triangle of the pass
 
     const uint32_t lane = threadIdx.x;
     const uint32_t nbx = P.fb.nbx, nbins = nbx * P.fb.nby;
@@ -128,6 +139,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     uint32_t col[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { dep[i] = P.clear_depth; col[i] = P.clear_rgba8; }
+    for (uint32_t i = lane; i < MTR_BIN * MTR_BIN; i += 64) s_cnt[i] = 0u;
 
     uint32_t seg_lo, S, ent_lo, n_ent;
     bin_queue(P.fb, bin, ent_lo, n_ent, seg_lo, S);
@@ -223,6 +235,141 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                     setup_entry<TEX>(P, r, binx0, biny0, s_tc[lane], TEX ? &s_tx[lane] : nullptr, s_chi[lane], s_mask[lane]);
                 }
                 wave_lds_sync();
+                // ---- fragment-list path: a pass of small triangles.  The (triangle, pixel) pairs of the pass are spread
+                //      over the wave 64 at a time (as in k_tile_vis.hip); every covered pair appends its triangle number to
+                //      its pixel's list; then lane = pixel walks its own short list in submission order: depth test,
+                //      shade, blend.  A whole-wave visit per (triangle, 8x8 sub-tile) -- the loop below -- costs the same
+                //      for a 2-pixel sliver as for a full sub-tile; this path costs per covered pixel.  Passes with a
+                //      64-bit-edge triangle, more than 2048 pairs, or a pixel hit more than FRAG_K times take the loop. ----
+                bool listed = false;
+                {
+                    const uint32_t box = lane < cntp ? s_tc[lane].pad : 0u;
+                    const uint32_t bw = ((box >> 8) & 15u) + 1u, bh = ((box >> 12) & 15u) + 1u;
+                    const uint32_t mine = (box >> 16) ? bw * bh : 0u;
+                    const bool large = lane < cntp && (s_tc[lane].flags & TF_LARGE);
+                    const uint32_t inc = wave_incl_scan_u32(mine);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    if (!__ballot(large) && total != 0 && total <= 2048u) {
+                        const uint64_t nzm = __ballot(mine != 0);
+                        const uint32_t cidx = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
+                        const uint32_t pre = inc - mine;
+                        if (lane < 32) s_start[lane] = 0ull;
+                        wave_lds_sync();
+                        if (mine) {
+                            s_tmap[cidx] = (uint8_t)lane;
+                            s_pm[lane] = pre | (((65536u + bw - 1u) / bw) << 12);  // exact k / bw for k < 256, bw <= 16
+                            atomicOr(&s_start[pre >> 6], 1ull << (pre & 63u));
+                        }
+                        wave_lds_sync();
+                        const unsigned long long my_start = lane < 32 ? s_start[lane] : 0ull;
+                        const uint32_t nbat = (total + 63u) >> 6;
+                        uint32_t base = 0;
+                        for (uint32_t b = 0; b < nbat; b++) {
+                            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_start, b);
+                            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_start >> 32), b);
+                            const uint64_t mm = ((uint64_t)mhi << 32) | mlo;
+                            const uint32_t ci = base + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (uint32_t)((mm >> lane) & 1ull) - 1u;
+                            base += (uint32_t)__popcll(mm);
+                            const uint32_t pidx = b * 64u + lane;
+                            if (pidx < total) {
+                                const uint32_t t = s_tmap[ci];
+                                const int4* tc = reinterpret_cast<const int4*>(&s_tc[t]);
+                                const int4 q0 = tc[0], q1 = tc[1], q2 = tc[2], q3 = tc[3];
+                                const uint32_t tb = (uint32_t)q3.w, pm = s_pm[t];
+                                const uint32_t k = pidx - (pm & 0xfffu);
+                                const uint32_t row = (k * (pm >> 12)) >> 16;
+                                const int32_t lx = (int32_t)((tb & 15u) + (k - row * (((tb >> 8) & 15u) + 1u)));
+                                const int32_t ly = (int32_t)(((tb >> 4) & 15u) + row);
+                                const int32_t eb0 = q0.z + __mul24(q0.x, lx) + __mul24(q0.y, ly);
+                                const int32_t eb1 = q1.y + __mul24(q0.w, lx) + __mul24(q1.x, ly);
+                                const int32_t eb2 = q2.x + __mul24(q1.z, lx) + __mul24(q1.w, ly);
+                                if ((eb0 | eb1 | eb2) >= 0) {
+                                    const uint32_t pix = (uint32_t)(ly * MTR_BIN + lx);
+                                    const uint32_t slot = atomicAdd(&s_cnt[pix], 1u);
+                                    if (slot < FRAG_K) s_frag[pix * FRAG_K + slot] = (uint8_t)t;
+                                }
+                            }
+                        }
+                        wave_lds_sync();
+                        uint32_t cn[4];
+                        bool over = false;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const uint32_t pix = (uint32_t)(((i >> 1) * 8 + (lane >> 3)) * MTR_BIN + (i & 1) * 8 + (lane & 7));
+                            cn[i] = s_cnt[pix];
+                            s_cnt[pix] = 0u;
+                            over = over || cn[i] > FRAG_K;
+                        }
+                        if (!__ballot(over)) {
+                            listed = true;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int32_t lx = (int32_t)((i & 1) * 8 + (lane & 7)), ly = (int32_t)((i >> 1) * 8 + (lane >> 3));
+                                const uint32_t pix = (uint32_t)(ly * MTR_BIN + lx);
+                                const bool in_vp = (uint32_t)(binx0 + lx) < P.fb.W && (uint32_t)(biny0 + ly) < P.fb.H;
+                                const uint2 fl = *reinterpret_cast<const uint2*>(&s_frag[pix * FRAG_K]);
+                                const uint32_t n = in_vp ? cn[i] : 0u;
+                                int32_t last = -1;
+                                for (;;) {
+                                    // the smallest triangle number above `last` in this pixel's list: submission order
+                                    uint32_t best = 255u;
+#pragma unroll
+                                    for (uint32_t j = 0; j < FRAG_K; j++) {
+                                        const uint32_t f = ((j < 4 ? fl.x : fl.y) >> (8u * (j & 3u))) & 0xffu;
+                                        if (j < n && (int32_t)f > last && f < best) best = f;
+                                    }
+                                    if (!__ballot(best != 255u)) break;
+                                    if (best == 255u) continue;
+                                    last = (int32_t)best;
+                                    const int4* tc = reinterpret_cast<const int4*>(&s_tc[best]);
+                                    const int4 q0 = tc[0], q1 = tc[1], q2 = tc[2], q3 = tc[3];
+                                    const uint32_t flags = (uint32_t)q2.y;
+                                    const float z0 = __int_as_float(q2.z), dz1 = __int_as_float(q2.w), dz2 = __int_as_float(q3.x),
+                                                rcpA = __int_as_float(q3.y);
+                                    // barycentrics at pixel (x, y) of the bin: the arithmetic of the loop below, lane by lane
+                                    auto bary = [&](int32_t x, int32_t y, float& b1, float& b2) {
+                                        const int32_t e1 = q1.y + __mul24(q0.w, x) + __mul24(q1.x, y);
+                                        const int32_t e2 = q2.x + __mul24(q1.z, x) + __mul24(q1.w, y);
+                                        b1 = (float)(e1 + (int32_t)((flags >> 5) & 1u)) * rcpA;
+                                        b2 = (float)(e2 + (int32_t)((flags >> 6) & 1u)) * rcpA;
+                                    };
+                                    float b1, b2;
+                                    bary(lx, ly, b1, b2);
+                                    const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
+                                    if (!(z >= 0.0f && z <= 1.0f && z <= dep[i])) continue;
+                                    dep[i] = z;
+                                    if (!TEX || !(flags & TF_TEX)) {
+                                        col[i] = (uint32_t)q3.z;
+                                    } else {
+                                        const TriX& Xt = s_tx[TEX ? best : 0];
+                                        auto uv_at = [&](int32_t x, int32_t y, float& u, float& v) {
+                                            float c1, c2;
+                                            bary(x, y, c1, c2);
+                                            const float iw = fmaf(c2, Xt.diw2, fmaf(c1, Xt.diw1, Xt.iw0));
+                                            const float up = fmaf(c2, Xt.dup2, fmaf(c1, Xt.dup1, Xt.up0));
+                                            const float vp = fmaf(c2, Xt.dvp2, fmaf(c1, Xt.dvp1, Xt.vp0));
+                                            u = up / iw;
+                                            v = vp / iw;
+                                        };
+                                        float u, v, ua, va, ub, vb;
+                                        uv_at(lx, ly, u, v);
+                                        uv_at(lx & ~1, ly, ua, va);
+                                        uv_at(lx | 1, ly, ub, vb);
+                                        const float dudx = ub - ua, dvdx = vb - va;
+                                        uv_at(lx, ly & ~1, ua, va);
+                                        uv_at(lx, ly | 1, ub, vb);
+                                        const float dudy = ub - ua, dvdy = vb - va;
+                                        const TexRef tr = {Xt.tex, Xt.tw, Xt.th};
+                                        float src[4];
+                                        sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, tr.tw, tr.th), src);
+                                        col[i] = blend_store(col[i], src, (flags & TF_BLEND) != 0);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (listed) { wave_lds_sync(); continue; }
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int32_t lx = (int32_t)((i & 1) * 8 + (lane & 7)), ly = (int32_t)((i >> 1) * 8 + (lane >> 3));
