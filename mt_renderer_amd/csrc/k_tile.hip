@@ -19,7 +19,9 @@
 namespace mtr {
 
 #define TRI_PASS 64
-#define FRAG_K 8u  // fragment-list path: triangle numbers kept per pixel and pass
+#ifndef FRAG_K
+#define FRAG_K 8u  // fragment-list path: triangle numbers kept per pixel and pass (4, 8 or 16)
+#endif
 
 // per-triangle set-up in LDS.  TriC (64 B) is read by every (triangle, sub-tile) visit as four
 // broadcast ds_read_b128; TriX (64 B) only by textured triangles.
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     __shared__ Seg s_seg[64];
     // fragment-list path: per pixel a count and up to FRAG_K triangle numbers of the current pass
     __shared__ uint32_t s_cnt[MTR_BIN * MTR_BIN];
-    __shared__ uint8_t s_frag[MTR_BIN * MTR_BIN * FRAG_K];
+    __shared__ __align__(16) uint8_t s_frag[MTR_BIN * MTR_BIN * FRAG_K];
     __shared__ unsigned long long s_start[32];  // <= 2048 pairs per pass: 32 batches of 64
     __shared__ uint32_t s_pm[TRI_PASS];         // pair prefix | magic(bbox width) << 12
     __shared__ uint8_t s_tmap[TRI_PASS];        // compacted index -> triangle of the pass
@@ -307,7 +309,9 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                                 const int32_t lx = (int32_t)((i & 1) * 8 + (lane & 7)), ly = (int32_t)((i >> 1) * 8 + (lane >> 3));
                                 const uint32_t pix = (uint32_t)(ly * MTR_BIN + lx);
                                 const bool in_vp = (uint32_t)(binx0 + lx) < P.fb.W && (uint32_t)(biny0 + ly) < P.fb.H;
-                                const uint2 fl = *reinterpret_cast<const uint2*>(&s_frag[pix * FRAG_K]);
+                                uint32_t fw[FRAG_K / 4];
+#pragma unroll
+                                for (uint32_t j = 0; j < FRAG_K / 4; j++) fw[j] = reinterpret_cast<const uint32_t*>(&s_frag[pix * FRAG_K])[j];
                                 const uint32_t n = in_vp ? cn[i] : 0u;
                                 int32_t last = -1;
                                 for (;;) {
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                                     uint32_t best = 255u;
 #pragma unroll
                                     for (uint32_t j = 0; j < FRAG_K; j++) {
-                                        const uint32_t f = ((j < 4 ? fl.x : fl.y) >> (8u * (j & 3u))) & 0xffu;
+                                        const uint32_t f = (fw[j >> 2] >> (8u * (j & 3u))) & 0xffu;
                                         if (j < n && (int32_t)f > last && f < best) best = f;
                                     }
                                     if (!__ballot(best != 255u)) break;

@@ -9,7 +9,12 @@ dev = api.Device(0)
 KERNEL_NAMES = {1: 'ordered', 2: 'vis', 3: 'mixed'}
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""  # optional substring filter on the config name
+
+
 def run(name, w, h, md, draw, nframes=30):
+    if ONLY not in name:
+        return
     m = api.Model.new(dev, md)
     batch = None
     if "model_mats" in draw:
