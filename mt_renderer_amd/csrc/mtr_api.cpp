@@ -75,6 +75,7 @@ struct mtr_device {
     static constexpr uint32_t kMaxInflight = 64;
     hipEvent_t inflight[kMaxInflight] = {};
     uint32_t max_inflight = 16;
+    uint64_t frames_submitted = 0;  // index of the next frame; frame i records inflight[i % max_inflight]
     hipStream_t s_copy = nullptr;  // small read-backs of finished frames (statistics), independent of frames in flight
     uint32_t frame_counter = 0;
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
@@ -99,8 +100,18 @@ struct mtr_model {
     uint16_t* d_ibuf = nullptr;
     DPrim* d_prims = nullptr;
     DChunk* d_chunks = nullptr;
-    float* d_palette = nullptr;
+    float* d_palette = nullptr;   // the current palette: one buffer of pal_ring
     uint32_t npal = 0;
+    // mtr_model_set_palette does not wait for frames in flight: every call uploads into the next buffer of a ring
+    // (max_inflight + 1 of them) on the copy stream and records an event; a frame captures pointer + event when the
+    // model is drawn and its stream waits on the event.  A ring buffer comes round again only after max_inflight + 1
+    // palette changes; if the last frame that read it can still be in flight (many changes, few frames) the call waits
+    // for exactly that frame first.
+    struct PalBuf { float* d = nullptr; uint32_t cap = 0; hipEvent_t ready = nullptr; uint64_t last_frame = 0; bool used = false; };
+    std::vector<PalBuf> pal_ring;
+    size_t pal_next = 0;
+    hipEvent_t pal_ready = nullptr;  // of the current palette
+    int pal_slot = -1;               // its index in pal_ring
     std::vector<DPrim> prims;
     std::vector<uint16_t> indices;
     std::vector<uint32_t> run;  // consecutive non-restart indices ending at each position
@@ -132,6 +143,8 @@ struct Draw {
     mtr_model* model;
     const float* d_model_mats;  // nullptr: M = view_proj
     const float* d_palettes;
+    hipEvent_t pal_ready;  // upload of d_palettes (model palettes; batch palettes are resident before the batch exists)
+    int pal_slot;          // ring buffer of the model palette, or -1
     uint32_t npal, pal_stride, ninst;
     float vp[16];
     std::vector<int32_t> tex_override;  // per instance or empty
@@ -532,7 +545,11 @@ void mtr_model_destroy(mtr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->dev->hip_dev);
     (void)hipStreamSynchronize(m->dev->stream);
-    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks, m->d_palette};
+    for (auto& pb : m->pal_ring) {
+        if (pb.d) (void)hipFree(pb.d);
+        if (pb.ready) (void)hipEventDestroy(pb.ready);
+    }
+    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -551,13 +568,33 @@ int32_t mtr_model_set_palette(mtr_model* m, const float* mats, size_t n) {
     if (n > 256 || (!mats && n)) return fail(d, MTR_E_INVALID, "palette: at most 256 matrices (u8 joint indices)");
     int32_t rc = set_device(d);
     if (rc) return rc;
-    HIPCHK(d, hipStreamSynchronize(d->stream));
-    if (m->d_palette) { (void)hipFree(m->d_palette); m->d_palette = nullptr; }
     m->npal = (uint32_t)n;
+    m->d_palette = nullptr;
+    m->pal_ready = nullptr;
+    m->pal_slot = -1;
     if (n) {
-        if ((rc = dev_alloc(d, &m->d_palette, n * 16))) return rc;
-        HIPCHK(d, hipMemcpyAsync(m->d_palette, mats, n * 64, hipMemcpyHostToDevice, d->stream));
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        if (m->pal_ring.size() != (size_t)d->max_inflight + 1) {  // first use (the bound is fixed at device creation)
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+            m->pal_ring.resize((size_t)d->max_inflight + 1);
+        }
+        const size_t slot = m->pal_next++ % m->pal_ring.size();
+        mtr_model::PalBuf& pb = m->pal_ring[slot];
+        // the last frame that read this buffer: finished for sure once max_inflight later frames have been submitted
+        if (pb.used && d->frames_submitted < pb.last_frame + 1 + d->max_inflight && d->inflight[pb.last_frame % d->max_inflight])
+            HIPCHK(d, hipEventSynchronize(d->inflight[pb.last_frame % d->max_inflight]));
+        if (pb.cap < n) {  // grow: nothing in flight may still read the old buffer
+            HIPCHK(d, hipStreamSynchronize(d->stream));
+            if (pb.d) (void)hipFree(pb.d);
+            pb.d = nullptr; pb.cap = 0;
+            if ((rc = dev_alloc(d, &pb.d, std::max<size_t>(n, 64) * 16))) return rc;
+            pb.cap = (uint32_t)std::max<size_t>(n, 64);
+        }
+        if (!pb.ready) HIPCHK(d, hipEventCreateWithFlags(&pb.ready, hipEventDisableTiming));
+        HIPCHK(d, hipMemcpyAsync(pb.d, mats, n * 64, hipMemcpyHostToDevice, d->s_copy));
+        HIPCHK(d, hipEventRecord(pb.ready, d->s_copy));
+        m->d_palette = pb.d;
+        m->pal_ready = pb.ready;
+        m->pal_slot = (int)slot;
     }
     return MTR_OK;
 }
@@ -685,7 +722,7 @@ int32_t mtr_frame_draw_model(mtr_frame* f, mtr_model* m, const float view_proj[1
     int32_t rc = check_model_for_draw(f, m);
     if (rc) return rc;
     Draw dr{};
-    dr.model = m; dr.d_model_mats = nullptr; dr.d_palettes = m->d_palette; dr.npal = m->npal;
+    dr.model = m; dr.d_model_mats = nullptr; dr.d_palettes = m->d_palette; dr.npal = m->npal; dr.pal_ready = m->pal_ready; dr.pal_slot = m->pal_slot;
     dr.pal_stride = 0; dr.ninst = 1; dr.shader_override = -1; dr.blend = true;
     memcpy(dr.vp, view_proj, sizeof dr.vp);
     f->draws.push_back(std::move(dr));
@@ -778,7 +815,8 @@ static int32_t run_frame(mtr_frame* f) {
     // fewer than 2^25 - 1 chunks (2 G triangles) per frame
     if (total_chunks >= (1ull << 25) - 1) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one frame");
     // this frame's slot: the other slots may still be feeding earlier frames' tile kernels
-    hipEvent_t& ring = d->inflight[d->frame_counter % d->max_inflight];
+    const uint64_t this_frame = d->frames_submitted++;
+    hipEvent_t& ring = d->inflight[this_frame % d->max_inflight];
     if (ring) HIPCHK(d, hipEventSynchronize(ring));  // frame (i - max_inflight) has left the GPU
     else HIPCHK(d, hipEventCreateWithFlags(&ring, hipEventDisableTiming));
     f->slot = (int)(d->frame_counter++ % d->nslots);
@@ -913,6 +951,13 @@ static int32_t run_frame(mtr_frame* f) {
         GeomParams gp{};
         gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = m->d_chunks;
         gp.nchunks = (uint32_t)m->chunks.size(); gp.ninst = dr.ninst;
+        if (dr.pal_ready) {  // a model palette from the ring (batch palettes are resident before the batch exists)
+            HIPCHK(d, hipStreamWaitEvent(sg, dr.pal_ready, 0));
+            if (dr.pal_slot >= 0 && (size_t)dr.pal_slot < m->pal_ring.size()) {
+                m->pal_ring[(size_t)dr.pal_slot].last_frame = this_frame;
+                m->pal_ring[(size_t)dr.pal_slot].used = true;
+            }
+        }
         gp.model_mats = dr.d_model_mats; gp.palettes = dr.d_palettes; gp.npal = dr.d_palettes ? dr.npal : 0;
         gp.pal_stride = dr.pal_stride;
         memcpy(gp.vp, dr.vp, sizeof gp.vp);
@@ -1137,6 +1182,7 @@ int32_t mtr_model_vertex_stage(mtr_model* m, size_t prim, const float M[16], flo
     gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.ninst = 1;
     gp.palettes = m->d_palette; gp.npal = m->d_palette ? m->npal : 0;
     memcpy(gp.vp, M, sizeof gp.vp);
+    if (m->pal_ready) HIPCHK(d, hipStreamWaitEvent(d->stream, m->pal_ready, 0));
     mtr_launch_vertex_stage(gp, (uint32_t)prim, d_clip, d_uv, d->stream);
     HIPCHK(d, hipGetLastError());
     HIPCHK(d, hipMemcpyAsync(out_clip, d_clip, (size_t)nv * 16, hipMemcpyDeviceToHost, d->stream));

@@ -509,3 +509,49 @@ def test_frames_in_flight_keep_their_own_pixels(gpu_device):
                 fr.close()
     finally:
         m.close()
+
+
+def test_palette_changes_between_frames_in_flight(gpu_device):
+    """An animated model: a new bone palette before every frame, forty frames submitted without waiting (more palette
+    changes than the library's ring of palette buffers holds, so buffers are reused while frames are in flight), then
+    read in reverse; every frame must show ITS palette.  A second model gets many palette changes and few frames."""
+    from mt_renderer_amd import api
+    w, h = 200, 120
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=14, cols=20)
+    M = scene.to_f32_colmajor(scene.headline_transform(w, h))
+    m = api.Model.new(gpu_device, md)
+    m2 = api.Model.new(gpu_device, md)
+    try:
+        frames, pals = [], []
+        for k in range(40):
+            pal = scene.bone_palette(t=0.05 * k)
+            m.set_palette(pal)
+            fr = api.Frame(gpu_device, w, h)
+            m.render(fr, M)
+            fr.submit()
+            frames.append(fr)
+            pals.append(pal)
+        for k in reversed(range(40)):
+            ref = render_oracle(w, h, [dict(md=md, M=M, palette=pals[k])]) if k % 4 == 0 else None
+            frames[k].wait()
+            if ref is not None:
+                assert_same((frames[k].color(), frames[k].depth(), frames[k].stats()), ref, f"animated frame {k}")
+            frames[k].close()
+        # many palette changes per frame: a buffer comes round while the one frame that read it may still run
+        got = []
+        for k in range(3):
+            pal = scene.bone_palette(t=0.3 + 0.2 * k)
+            m2.set_palette(pal)
+            fr = api.Frame(gpu_device, w, h)
+            m2.render(fr, M)
+            fr.submit()
+            for j in range(25):
+                m2.set_palette(scene.bone_palette(t=1.0 + 0.01 * j))  # overwrites the whole ring
+            got.append((fr, pal))
+        for fr, pal in got:
+            fr.wait()
+            assert_same((fr.color(), fr.depth(), fr.stats()), render_oracle(w, h, [dict(md=md, M=M, palette=pal)]), "frame under palette churn")
+            fr.close()
+    finally:
+        m.close()
+        m2.close()
