@@ -76,6 +76,8 @@ struct mtr_device {
     hipEvent_t inflight[kMaxInflight] = {};
     uint32_t max_inflight = 16;
     uint64_t frames_submitted = 0;  // index of the next frame; frame i records inflight[i % max_inflight]
+    struct Garbage { void* p; uint64_t last_frame; };
+    std::vector<Garbage> garbage;   // device buffers of destroyed batches whose last frame may still be in flight
     hipStream_t s_copy = nullptr;  // small read-backs of finished frames (statistics), independent of frames in flight
     uint32_t frame_counter = 0;
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
@@ -133,6 +135,9 @@ struct mtr_batch {
     float* d_palettes = nullptr;
     uint32_t npal = 0;
     std::vector<int32_t> tex_override;
+    hipEvent_t ready = nullptr;  // the uploads (copy stream); frames that draw the batch wait on it
+    uint64_t last_frame = 0;     // last frame that drew it: its buffers are freed only once that frame has left the GPU
+    bool used = false;
 };
 
 struct BatchDeleter {
@@ -143,7 +148,8 @@ struct Draw {
     mtr_model* model;
     const float* d_model_mats;  // nullptr: M = view_proj
     const float* d_palettes;
-    hipEvent_t pal_ready;  // upload of d_palettes (model palettes; batch palettes are resident before the batch exists)
+    hipEvent_t pal_ready;  // upload of d_palettes / d_model_mats on the copy stream (model palette ring, or the batch)
+    mtr_batch* batch;      // drawn batch (not owned unless owned_batch), for its last-use bookkeeping
     int pal_slot;          // ring buffer of the model palette, or -1
     uint32_t npal, pal_stride, ninst;
     float vp[16];
@@ -323,6 +329,7 @@ void mtr_device_destroy(mtr_device* d) {
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
     for (hipEvent_t e : d->inflight)
         if (e) (void)hipEventDestroy(e);
+    for (auto& g : d->garbage) (void)hipFree(g.p);
     if (d->s_copy) (void)hipStreamDestroy(d->s_copy);
     if (d->cube) mtr_model_destroy(d->cube);
     for (auto& f : d->free_fb) {
@@ -619,22 +626,31 @@ int32_t mtr_batch_create(mtr_device* d, mtr_model* model, size_t n, const float*
     int32_t rc = set_device(d);
     if (rc) return rc;
     if ((rc = dev_alloc(d, &b->d_model_mats, n * 16))) return rc;
-    HIPCHK(d, hipMemcpyAsync(b->d_model_mats, model_mats, n * 64, hipMemcpyHostToDevice, d->stream));
+    // uploads go through the copy stream and an event: creating a batch does not wait for frames in flight
+    HIPCHK(d, hipMemcpyAsync(b->d_model_mats, model_mats, n * 64, hipMemcpyHostToDevice, d->s_copy));
     if (b->npal) {
         if ((rc = dev_alloc(d, &b->d_palettes, n * npal * 16))) return rc;
-        HIPCHK(d, hipMemcpyAsync(b->d_palettes, palettes, n * npal * 64, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(d, hipMemcpyAsync(b->d_palettes, palettes, n * npal * 64, hipMemcpyHostToDevice, d->s_copy));
     }
-    HIPCHK(d, hipStreamSynchronize(d->stream));
+    HIPCHK(d, hipEventCreateWithFlags(&b->ready, hipEventDisableTiming));
+    HIPCHK(d, hipEventRecord(b->ready, d->s_copy));
     *out = b.release();
     return MTR_OK;
 }
 
 void mtr_batch_destroy(mtr_batch* b) {
     if (!b) return;
-    (void)hipSetDevice(b->dev->hip_dev);
-    (void)hipStreamSynchronize(b->dev->stream);
-    if (b->d_model_mats) (void)hipFree(b->d_model_mats);
-    if (b->d_palettes) (void)hipFree(b->d_palettes);
+    mtr_device* d = b->dev;
+    (void)hipSetDevice(d->hip_dev);
+    // a frame that drew the batch may still be in flight: park the buffers until that frame has left the GPU
+    // (collected at a later submit); otherwise free them now.  No stream is drained either way.
+    const bool busy = b->used && d->frames_submitted <= b->last_frame + d->max_inflight;
+    for (void* p : {(void*)b->d_model_mats, (void*)b->d_palettes})
+        if (p) {
+            if (busy) d->garbage.push_back({p, b->last_frame});
+            else (void)hipFree(p);
+        }
+    if (b->ready) (void)hipEventDestroy(b->ready);
     delete b;
 }
 
@@ -735,7 +751,7 @@ int32_t mtr_frame_draw_batch(mtr_frame* f, mtr_batch* b, const float view_proj[1
     int32_t rc = check_model_for_draw(f, b->model);
     if (rc) return rc;
     Draw dr{};
-    dr.model = b->model; dr.d_model_mats = b->d_model_mats;
+    dr.model = b->model; dr.d_model_mats = b->d_model_mats; dr.batch = b; dr.pal_ready = b->ready; dr.pal_slot = -1;
     dr.d_palettes = b->npal ? b->d_palettes : nullptr;
     dr.npal = b->npal; dr.pal_stride = b->npal * 16; dr.ninst = b->n;
     dr.tex_override = b->tex_override; dr.shader_override = -1; dr.blend = true;
@@ -819,6 +835,15 @@ static int32_t run_frame(mtr_frame* f) {
     hipEvent_t& ring = d->inflight[this_frame % d->max_inflight];
     if (ring) HIPCHK(d, hipEventSynchronize(ring));  // frame (i - max_inflight) has left the GPU
     else HIPCHK(d, hipEventCreateWithFlags(&ring, hipEventDisableTiming));
+    // every frame up to this_frame - max_inflight has been waited for: collect what only they could still read
+    if (!d->garbage.empty()) {
+        size_t keep = 0;
+        for (auto& g : d->garbage) {
+            if (g.last_frame + d->max_inflight <= this_frame) (void)hipFree(g.p);
+            else d->garbage[keep++] = g;
+        }
+        d->garbage.resize(keep);
+    }
     f->slot = (int)(d->frame_counter++ % d->nslots);
     Slot& sl = d->slots[f->slot];
     const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
@@ -951,7 +976,8 @@ static int32_t run_frame(mtr_frame* f) {
         GeomParams gp{};
         gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = m->d_chunks;
         gp.nchunks = (uint32_t)m->chunks.size(); gp.ninst = dr.ninst;
-        if (dr.pal_ready) {  // a model palette from the ring (batch palettes are resident before the batch exists)
+        if (dr.batch) { dr.batch->last_frame = this_frame; dr.batch->used = true; }
+        if (dr.pal_ready) {  // uploads of a model palette (ring) or of a batch, made on the copy stream
             HIPCHK(d, hipStreamWaitEvent(sg, dr.pal_ready, 0));
             if (dr.pal_slot >= 0 && (size_t)dr.pal_slot < m->pal_ring.size()) {
                 m->pal_ring[(size_t)dr.pal_slot].last_frame = this_frame;

@@ -555,3 +555,41 @@ def test_palette_changes_between_frames_in_flight(gpu_device):
     finally:
         m.close()
         m2.close()
+
+
+def test_dynamic_instances_between_frames_in_flight(gpu_device):
+    """Per-frame instance matrices: twenty-four frames, each drawing its own freshly uploaded instances -- odd frames
+    through a Batch that is destroyed right after submit (its buffers must outlive the frame that is still in flight),
+    even frames through draw_instances (a batch owned by the frame, which is destroyed in flight too) -- submitted
+    without waiting; then every fourth one is compared with the oracle."""
+    from mt_renderer_amd import api
+    w, h = 240, 136
+    md = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=10, cols=16)
+    vp = scene.to_f32_colmajor(scene.reference_view_proj(w, h))
+    m = api.Model.new(gpu_device, md)
+    try:
+        frames, args = [], []
+        for k in range(24):
+            mats, pals = scene.instance_lattice(3, 2, seed=100 + k)
+            fr = api.Frame(gpu_device, w, h)
+            if k % 2:
+                b = api.Batch(gpu_device, m, mats, pals)
+                fr.draw_batch(b, vp)
+                fr.submit()
+                b.close()
+            else:
+                fr.draw_instances(m, vp, mats, pals)
+                fr.submit()
+            frames.append(fr)
+            args.append((mats, pals))
+        colors = {}
+        for k in reversed(range(24)):
+            frames[k].wait()
+            if k % 4 < 2:
+                colors[k] = (frames[k].color(), frames[k].depth(), frames[k].stats())
+            frames[k].close()
+        for k, got in colors.items():
+            mats, pals = args[k]
+            assert_same(got, render_oracle(w, h, [dict(md=md, vp=vp, model_mats=mats, palettes=pals)]), f"dynamic instances, frame {k}")
+    finally:
+        m.close()
