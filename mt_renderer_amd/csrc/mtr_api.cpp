@@ -1103,8 +1103,9 @@ int32_t mtr_frame_read_color(mtr_frame* f, void* rgba8, size_t len) {
     if (len < (size_t)f->w * f->h * 4) return fail(d, MTR_E_INVALID, "output too small");
     int32_t rc = mtr_frame_wait(f);
     if (rc) return rc;
-    HIPCHK(d, hipMemcpyAsync(rgba8, f->fb.color, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(d, hipStreamSynchronize(d->stream));
+    // the frame is complete (mtr_frame_wait): read it on the copy stream, not behind the later frames in flight
+    HIPCHK(d, hipMemcpyAsync(rgba8, f->fb.color, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->s_copy));
+    HIPCHK(d, hipStreamSynchronize(d->s_copy));
     return MTR_OK;
 }
 
@@ -1114,8 +1115,8 @@ int32_t mtr_frame_read_depth(mtr_frame* f, float* depth, size_t count) {
     if (count < (size_t)f->w * f->h) return fail(d, MTR_E_INVALID, "output too small");
     int32_t rc = mtr_frame_wait(f);
     if (rc) return rc;
-    HIPCHK(d, hipMemcpyAsync(depth, f->fb.depth, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK(d, hipStreamSynchronize(d->stream));
+    HIPCHK(d, hipMemcpyAsync(depth, f->fb.depth, (size_t)f->w * f->h * 4, hipMemcpyDeviceToHost, d->s_copy));
+    HIPCHK(d, hipStreamSynchronize(d->s_copy));
     return MTR_OK;
 }
 
