@@ -355,14 +355,14 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                                             u = up / iw;
                                             v = vp / iw;
                                         };
-                                        float u, v, ua, va, ub, vb;
+                                        // fine quad differences: (odd position) - (even position) along each axis; this
+                                        // pixel is one end of both, so two more evaluations give all four derivatives
+                                        float u, v, uh, vh, uw, vw;
                                         uv_at(lx, ly, u, v);
-                                        uv_at(lx & ~1, ly, ua, va);
-                                        uv_at(lx | 1, ly, ub, vb);
-                                        const float dudx = ub - ua, dvdx = vb - va;
-                                        uv_at(lx, ly & ~1, ua, va);
-                                        uv_at(lx, ly | 1, ub, vb);
-                                        const float dudy = ub - ua, dvdy = vb - va;
+                                        uv_at(lx ^ 1, ly, uh, vh);
+                                        uv_at(lx, ly ^ 1, uw, vw);
+                                        const float dudx = (lx & 1) ? u - uh : uh - u, dvdx = (lx & 1) ? v - vh : vh - v;
+                                        const float dudy = (ly & 1) ? u - uw : uw - u, dvdy = (ly & 1) ? v - vw : vw - v;
                                         const TexRef tr = {Xt.tex, Xt.tw, Xt.th};
                                         float src[4];
                                         sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, tr.tw, tr.th), src);

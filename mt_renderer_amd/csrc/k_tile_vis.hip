@@ -120,15 +120,14 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
         u = up / iw;
         v = vp / iw;
     };
-    float u, v, ua, va, ub, vb;
+    // fine quad differences: (odd position) - (even position) along each axis; this pixel is one end of both, so two
+    // more evaluations give all four derivatives
+    float u, v, uh, vh, uw, vw;
     uv_at(px, py, u, v);
-    const int32_t qx = px & ~1, qy = py & ~1;
-    uv_at(qx, py, ua, va);
-    uv_at(qx + 1, py, ub, vb);
-    const float dudx = ub - ua, dvdx = vb - va;
-    uv_at(px, qy, ua, va);
-    uv_at(px, qy + 1, ub, vb);
-    const float dudy = ub - ua, dvdy = vb - va;
+    uv_at(px ^ 1, py, uh, vh);
+    uv_at(px, py ^ 1, uw, vw);
+    const float dudx = (px & 1) ? u - uh : uh - u, dvdx = (px & 1) ? v - vh : vh - v;
+    const float dudy = (py & 1) ? u - uw : uw - u, dvdy = (py & 1) ? v - vw : vw - v;
     const TexRef tr = {mat.tex, mat.tw, mat.th};
     float src[4];
     sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, mat.tw, mat.th), src);
