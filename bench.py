@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 # HBM bytes per launch of the two heaviest kernels on the headline scene, from rocprofv3 PMC passes run separately
 # (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B,
 # MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_d_pmc_headline.csv).
-TRAFFIC_TILE_VIS = 55135642     # k_tile_vis<false>: 2 x 18370.4 KB fetched + 17102.6 KB written (framebuffer = 16.6 MB)
-TRAFFIC_GEOM_DIRECT = 61802394  # k_geom<2>:         2 x 8939.0 KB fetched + 42475.9 KB written (records, bin queues, scratch)
+TRAFFIC_TILE_VIS = 55451238     # k_tile_vis<false>: 2 x 18507.9 KB fetched + 17135.8 KB written (framebuffer = 16.6 MB)
+TRAFFIC_GEOM_DIRECT = 61785498  # k_geom<2>:         2 x 8939.4 KB fetched + 42458.6 KB written (records, bin queues, scratch)
 
 
 def algorithmic_bytes(md, width, height, npalettes, nbones=64):
