@@ -11,6 +11,7 @@
  *   rShader2  (.mfx)  src/rshader2.rs:14-66 (structs), :298-486 (Shader2File::new), sizes :573-582
  *   rMaterial (.mrl)  src/rmaterial.rs:12-116 (structs), :179-298 (MaterialFile::new), sizes :317-322
  *   rScheduler(.sdl)  src/rscheduler.rs:36-84 (structs), :88-216 (SchedulerFile::new), size :222
+ *   rArchive  (.arc)  src/rarchive.rs:24-43 (structs), :73-176 (ArchiveFile::new / get_resource), sizes :163-169
  *
  * All multi-byte fields are little-endian and unaligned ("repr(C, packed)" in the reference).  "View" structs
  * point INTO the caller's buffer, which must outlive them; their typed pointers (primitives, lmats, imats,
@@ -34,7 +35,7 @@ const char *mtr_files_last_error(void);
  * 6 TextureHeader 0x10, 7 Shader2Header 0x20, 8 RawShader2Object 0x28, 9 RawShader2InputElement 0x10,
  * 10 RawShader2InputLayout 16, 11 RawShader2Struct 16, 12 RawShader2Variable 0x30, 13 RawShader2CBuffer 24,
  * 14 MaterialHeader 0x28, 15 RawTextureInfo 0x98, 16 RawMaterialInfo 0x48, 17 RawMaterialState 0x18,
- * 18 SchedulerTrack 0x30, 19 SchedulerHeader 0x20.   Unknown kind: 0. */
+ * 18 SchedulerTrack 0x30, 19 SchedulerHeader 0x20, 20 ArchiveHeader 8, 21 RawResourceInfo 0x90.   Unknown kind: 0. */
 size_t mtr_file_struct_size(uint32_t kind);
 
 /* ---------------------------------------------------------------- rModel ---- */
@@ -151,6 +152,30 @@ int32_t mtr_rscheduler_key(const mtr_rscheduler *s, uint32_t track, uint32_t k, 
  * reference never evaluates tracks, so this rule is this build's and is documented as such).  MTR_E_INVALID if the
  * track has no key at or before `frame`. */
 int32_t mtr_rscheduler_eval(const mtr_rscheduler *s, uint32_t track, uint32_t frame, uint64_t *value_bits);
+
+/* -------------------------------------------------------------- rArchive ---- */
+/* ArchiveFile over a caller-owned file image (zlib-compressed resources behind a table of 0x90-byte entries).
+ * MTR_E_INVALID: magic != "ARC\0" or version != 7 (asserts at src/rarchive.rs:79-80), truncated table, path not
+ * terminated.  The view points INTO the caller's buffer. */
+typedef struct mtr_rarchive_view {
+    uint32_t num_resources;
+    const uint8_t *table;   /* num_resources x 0x90: path[128], dti_type, size_compressed, orgsize:29|quality:3, offset */
+    const uint8_t *file;    /* the archive image */
+    size_t file_len;
+} mtr_rarchive_view;
+typedef struct mtr_resource_info {
+    const char *path;       /* backslash-separated, no extension (src/rarchive.rs:138-141) */
+    uint32_t dti_hash;      /* resource class (crc32(name) & 0x7fffffff, src/dti.rs:174) */
+    uint32_t size_compressed, size_uncompressed, quality, offset;
+} mtr_resource_info;
+int32_t mtr_rarchive_parse(const void *data, size_t len, mtr_rarchive_view *out);
+int32_t mtr_rarchive_info(const mtr_rarchive_view *a, uint32_t i, mtr_resource_info *out);
+/* ArchiveFile::get_resource (src/rarchive.rs:143-176): index of the resource with this path ('/' accepted for '\\')
+ * and class hash, or -1 */
+int32_t mtr_rarchive_find(const mtr_rarchive_view *a, const char *path, uint32_t dti_hash);
+/* inflate resource i into out (capacity cap >= size_uncompressed).  MTR_E_INVALID: compressed bytes outside the file,
+ * corrupt stream, or a length other than size_uncompressed (assert at src/rarchive.rs:173) */
+int32_t mtr_rarchive_extract(const mtr_rarchive_view *a, uint32_t i, void *out, size_t cap, size_t *out_len);
 
 /* ------------------------------------------- Model::new from parsed files ---- */
 /* src/model.rs:36-293 over real files: per primitive the input layout is looked up in the shader package by

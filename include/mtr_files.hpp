@@ -1,6 +1,7 @@
 // mtr_files.hpp -- C++ mirror of the reference's resource readers over include/mtr_files.h, with the reference's type
 // names: ModelFile (src/rmodel.rs:295), TextureFile (src/rtexture.rs:80), Shader2File (src/rshader2.rs:246),
-// MaterialFile (src/rmaterial.rs:172), SchedulerFile (src/rscheduler.rs:84); Model::from_files = Model::new over them
+// MaterialFile (src/rmaterial.rs:172), SchedulerFile (src/rscheduler.rs:84), ArchiveFile (src/rarchive.rs:66);
+// model_from_files = Model::new over them
 // (src/model.rs:36-293).  Each reader owns a copy of the file bytes; errors (the reference's panics) throw mtr::Error.
 #pragma once
 #include "mtr.hpp"
@@ -131,6 +132,32 @@ class SchedulerFile {
   private:
     struct Del { void operator()(mtr_rscheduler* p) const { mtr_rscheduler_destroy(p); } };
     std::unique_ptr<mtr_rscheduler, Del> h_;
+};
+
+class ArchiveFile {
+  public:
+    explicit ArchiveFile(std::vector<uint8_t> bytes) : bytes_(std::move(bytes)) {
+        files_check(mtr_rarchive_parse(bytes_.data(), bytes_.size(), &v_));
+    }
+    uint32_t num_resources() const { return v_.num_resources; }
+    mtr_resource_info info(uint32_t i) const {
+        mtr_resource_info r{};
+        files_check(mtr_rarchive_info(&v_, i, &r));
+        return r;
+    }
+    // ArchiveFile::get_resource_with_path (src/rarchive.rs:130-141): empty optional-like result = {false, {}}
+    bool get_resource(const std::string& path, uint32_t dti_hash, std::vector<uint8_t>& out) const {
+        const int32_t i = mtr_rarchive_find(&v_, path.c_str(), dti_hash);
+        if (i < 0) return false;
+        out.resize(info((uint32_t)i).size_uncompressed);
+        size_t n = 0;
+        files_check(mtr_rarchive_extract(&v_, (uint32_t)i, out.data(), out.size(), &n));
+        return true;
+    }
+
+  private:
+    std::vector<uint8_t> bytes_;
+    mtr_rarchive_view v_{};
 };
 
 // Texture::new(device, queue, TextureFile) -- src/texture.rs:11

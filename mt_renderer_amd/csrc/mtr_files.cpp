@@ -14,6 +14,8 @@
 
 #include "../../include/mtr_files.h"
 
+#include <zlib.h>
+
 namespace {
 
 thread_local char g_err[256] = "";
@@ -105,6 +107,14 @@ struct SchedulerTrack {  // src/rscheduler.rs:37-49
     uint32_t field_10, pad_14;
     uint64_t unit_group, key_frame, key_value;
 };
+struct ArchiveHeader {  // src/rarchive.rs:24-30
+    uint32_t magic;
+    uint16_t version, num_resources;
+};
+struct RawResourceInfo {  // src/rarchive.rs:32-43
+    char path[128];
+    uint32_t dti_type, size_compressed, orgsize_quality, offset;
+};
 struct SchedulerHeader {  // src/rscheduler.rs:67-79
     uint32_t magic;
     uint16_t version, track_num;
@@ -130,6 +140,8 @@ static_assert(sizeof(RawMaterialInfo) == 0x48, "RawMaterialInfo");
 static_assert(sizeof(RawMaterialState) == 0x18, "RawMaterialState");
 static_assert(sizeof(SchedulerTrack) == 0x30, "SchedulerTrack");
 static_assert(sizeof(SchedulerHeader) == 0x20, "SchedulerHeader");
+static_assert(sizeof(ArchiveHeader) == 8, "ArchiveHeader");
+static_assert(sizeof(RawResourceInfo) == 0x90, "RawResourceInfo");
 
 constexpr size_t kPartsInfo = 0x20, kBoundaryInfo = 0x90, kMtMatrix = 64;
 
@@ -206,7 +218,7 @@ size_t mtr_file_struct_size(uint32_t kind) {
                                    sizeof(RawShader2InputElement), sizeof(RawShader2InputLayout), sizeof(RawShader2Struct),
                                    sizeof(RawShader2Variable), sizeof(RawShader2CBuffer), sizeof(MaterialHeader),
                                    sizeof(RawTextureInfo), sizeof(RawMaterialInfo), sizeof(RawMaterialState),
-                                   sizeof(SchedulerTrack), sizeof(SchedulerHeader)};
+                                   sizeof(SchedulerTrack), sizeof(SchedulerHeader), sizeof(ArchiveHeader), sizeof(RawResourceInfo)};
     return kind < sizeof sizes / sizeof sizes[0] ? sizes[kind] : 0;
 }
 
@@ -623,6 +635,67 @@ int32_t mtr_rscheduler_eval(const mtr_rscheduler* s, uint32_t track, uint32_t fr
     }
     if (best < 0) return ferr(MTR_E_INVALID, "rScheduler: track %u has no key at or before frame %u", track, frame);
     *value_bits = t.values[(size_t)best];
+    return MTR_OK;
+}
+
+// -------------------------------------------------------------------------------------------- rArchive
+int32_t mtr_rarchive_parse(const void* data, size_t len, mtr_rarchive_view* out) {
+    if (!data || !out) return ferr(MTR_E_INVALID, "rArchive: null argument");
+    const Span s{static_cast<const uint8_t*>(data), len};
+    ArchiveHeader h;
+    if (!rd(s, 0, h)) return ferr(MTR_E_INVALID, "rArchive: truncated header");
+    if (memcmp(&h.magic, "ARC\0", 4) != 0) return ferr(MTR_E_INVALID, "rArchive: bad magic %08x", h.magic);
+    if (h.version != 7) return ferr(MTR_E_INVALID, "rArchive: version %u, expected 7", h.version);
+    const uint8_t* table = s.at(sizeof h, h.num_resources, sizeof(RawResourceInfo));
+    if (!table) return ferr(MTR_E_INVALID, "rArchive: resource table out of range");
+    for (uint32_t i = 0; i < h.num_resources; i++)
+        if (!memchr(table + (size_t)i * sizeof(RawResourceInfo), 0, 128)) return ferr(MTR_E_INVALID, "rArchive: path of resource %u is not terminated", i);
+    *out = mtr_rarchive_view{h.num_resources, table, s.p, len};
+    return MTR_OK;
+}
+
+int32_t mtr_rarchive_info(const mtr_rarchive_view* a, uint32_t i, mtr_resource_info* out) {
+    if (!a || !out || i >= a->num_resources) return ferr(MTR_E_INVALID, "rArchive: resource %u out of range", i);
+    const uint8_t* e = a->table + (size_t)i * sizeof(RawResourceInfo);
+    RawResourceInfo r;
+    memcpy(&r, e, sizeof r);
+    out->path = reinterpret_cast<const char*>(e);
+    out->dti_hash = r.dti_type;
+    out->size_compressed = r.size_compressed;
+    out->size_uncompressed = r.orgsize_quality & ((1u << 29) - 1u);  // ORGSIZE_MASK, src/rarchive.rs:19
+    out->quality = (r.orgsize_quality >> 29) & 7u;
+    out->offset = r.offset;
+    return MTR_OK;
+}
+
+int32_t mtr_rarchive_find(const mtr_rarchive_view* a, const char* path, uint32_t dti_hash) {
+    if (!a || !path) return -1;
+    std::string want(path);
+    for (char& c : want)
+        if (c == '/') c = '\\';  // get_resource_with_path, src/rarchive.rs:138-141
+    for (uint32_t i = 0; i < a->num_resources; i++) {
+        mtr_resource_info ri;
+        mtr_rarchive_info(a, i, &ri);
+        if (ri.dti_hash == dti_hash && want == ri.path) return (int32_t)i;
+    }
+    return -1;
+}
+
+int32_t mtr_rarchive_extract(const mtr_rarchive_view* a, uint32_t i, void* out, size_t cap, size_t* out_len) {
+    mtr_resource_info ri;
+    int32_t rc = mtr_rarchive_info(a, i, &ri);
+    if (rc) return rc;
+    if (!out && ri.size_uncompressed) return ferr(MTR_E_INVALID, "rArchive: null output");
+    if (cap < ri.size_uncompressed) return ferr(MTR_E_INVALID, "rArchive: output holds %zu bytes, resource %u needs %u", cap, i, ri.size_uncompressed);
+    const Span s{a->file, a->file_len};
+    const uint8_t* src = s.at(ri.offset, ri.size_compressed, 1);
+    if (!src) return ferr(MTR_E_INVALID, "rArchive: compressed bytes of resource %u lie outside the file", i);
+    uLongf n = (uLongf)cap;
+    static uint8_t dummy;
+    const int z = uncompress(static_cast<Bytef*>(out ? out : &dummy), &n, src, ri.size_compressed);  // zlib stream (flate2 ZlibDecoder)
+    if (z != Z_OK) return ferr(MTR_E_INVALID, "rArchive: resource %u does not inflate (zlib %d)", i, z);
+    if (n != ri.size_uncompressed) return ferr(MTR_E_INVALID, "rArchive: resource %u inflated to %lu bytes, table says %u", i, (unsigned long)n, ri.size_uncompressed);
+    if (out_len) *out_len = n;
     return MTR_OK;
 }
 

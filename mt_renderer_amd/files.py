@@ -23,13 +23,14 @@ EXPORTED_SYMBOLS = [
     "mtr_rmaterial_parse", "mtr_rmaterial_destroy", "mtr_rmaterial_num_textures", "mtr_rmaterial_texture_path",
     "mtr_rmaterial_num_materials", "mtr_rmaterial_info", "mtr_rmaterial_find", "mtr_rscheduler_parse",
     "mtr_rscheduler_destroy", "mtr_rscheduler_num_tracks", "mtr_rscheduler_track", "mtr_rscheduler_key",
-    "mtr_rscheduler_eval", "mtr_model_create_from_files",
+    "mtr_rscheduler_eval", "mtr_model_create_from_files", "mtr_rarchive_parse", "mtr_rarchive_info", "mtr_rarchive_find",
+    "mtr_rarchive_extract",
 ]
 
 STRUCT_KINDS = ["ModelHdr", "PrimitiveInfo", "PartsInfo", "BoundaryInfo", "JointInfo", "MtMatrix", "TextureHeader",
                 "Shader2Header", "RawShader2Object", "RawShader2InputElement", "RawShader2InputLayout", "RawShader2Struct",
                 "RawShader2Variable", "RawShader2CBuffer", "MaterialHeader", "RawTextureInfo", "RawMaterialInfo",
-                "RawMaterialState", "SchedulerTrack", "SchedulerHeader"]
+                "RawMaterialState", "SchedulerTrack", "SchedulerHeader", "ArchiveHeader", "RawResourceInfo"]
 
 (PRIM_VERTEX_NUM, PRIM_PARTS_NO, PRIM_MATERIAL_NO, PRIM_WEIGHT_NUM, PRIM_VERTEX_STRIDE, PRIM_TOPOLOGY, PRIM_VERTEX_OFS,
  PRIM_VERTEX_BASE, PRIM_INPUTLAYOUT, PRIM_INDEX_OFS, PRIM_INDEX_NUM, PRIM_INDEX_BASE, PRIM_BOUNDARY_NUM) = range(13)
@@ -72,6 +73,19 @@ class _TrackInfo(C.Structure):
                 ("dti_or_prop", C.c_uint32), ("name", C.c_char_p)]
 
 
+class _RArchiveView(C.Structure):
+    _fields_ = [("num_resources", C.c_uint32), ("table", C.c_void_p), ("file", C.c_void_p), ("file_len", C.c_size_t)]
+
+
+class _ResourceInfo(C.Structure):
+    _fields_ = [("path", C.c_char_p), ("dti_hash", C.c_uint32), ("size_compressed", C.c_uint32),
+                ("size_uncompressed", C.c_uint32), ("quality", C.c_uint32), ("offset", C.c_uint32)]
+
+
+lib.mtr_rarchive_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_RArchiveView)]
+lib.mtr_rarchive_info.argtypes = [C.POINTER(_RArchiveView), C.c_uint32, C.POINTER(_ResourceInfo)]
+lib.mtr_rarchive_find.argtypes = [C.POINTER(_RArchiveView), C.c_char_p, C.c_uint32]
+lib.mtr_rarchive_extract.argtypes = [C.POINTER(_RArchiveView), C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
 lib.mtr_files_last_error.restype = C.c_char_p
 lib.mtr_file_struct_size.restype = C.c_size_t
 lib.mtr_file_struct_size.argtypes = [C.c_uint32]
@@ -317,6 +331,37 @@ class SchedulerFile:
 
     def eval_float(self, track: int, frame: int) -> float:
         return float(np.array([self.eval(track, frame) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])
+
+
+class ArchiveFile:
+    """src/rarchive.rs:66-176: a table of zlib-compressed resources."""
+
+    def __init__(self, data: bytes):
+        self._b = _buf(data)
+        self.v = _RArchiveView()
+        _check(lib.mtr_rarchive_parse(self._b, len(data), C.byref(self.v)))
+
+    def resource_infos(self) -> List[dict]:
+        out = []
+        for i in range(self.v.num_resources):
+            ri = _ResourceInfo()
+            _check(lib.mtr_rarchive_info(C.byref(self.v), i, C.byref(ri)))
+            out.append(dict(path=ri.path.decode(errors="replace"), dti_hash=ri.dti_hash, size_compressed=ri.size_compressed,
+                            size_uncompressed=ri.size_uncompressed, quality=ri.quality, offset=ri.offset))
+        return out
+
+    def get_resource(self, path: str, dti_hash: int) -> Optional[bytes]:
+        """ArchiveFile::get_resource_with_path: None when the archive has no such (path, class)."""
+        i = lib.mtr_rarchive_find(C.byref(self.v), path.encode(), dti_hash & 0xFFFFFFFF)
+        return None if i < 0 else self.extract(i)
+
+    def extract(self, i: int) -> bytes:
+        ri = _ResourceInfo()
+        _check(lib.mtr_rarchive_info(C.byref(self.v), i, C.byref(ri)))
+        out = (C.c_uint8 * max(1, ri.size_uncompressed))()
+        n = C.c_size_t()
+        _check(lib.mtr_rarchive_extract(C.byref(self.v), i, out, ri.size_uncompressed, C.byref(n)))
+        return bytes(out[:n.value])
 
 
 def model_from_files(dev: api.Device, model: ModelFile, shader2: Shader2File, material: Optional[MaterialFile],

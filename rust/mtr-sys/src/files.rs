@@ -81,6 +81,24 @@ pub struct mtr_track_info {
     pub name: *const c_char,
 }
 
+#[repr(C)]
+pub struct mtr_rarchive_view {
+    pub num_resources: u32,
+    pub table: *const u8,
+    pub file: *const u8,
+    pub file_len: usize,
+}
+
+#[repr(C)]
+pub struct mtr_resource_info {
+    pub path: *const c_char,
+    pub dti_hash: u32,
+    pub size_compressed: u32,
+    pub size_uncompressed: u32,
+    pub quality: u32,
+    pub offset: u32,
+}
+
 pub enum mtr_rshader2 {}
 pub enum mtr_rmaterial {}
 pub enum mtr_rscheduler {}
@@ -115,6 +133,10 @@ extern "C" {
     pub fn mtr_rscheduler_key(s: *const mtr_rscheduler, track: u32, k: u32, frame: *mut u32, mode: *mut u32, value_bits: *mut u64,
                               resource: *mut *const c_char) -> i32;
     pub fn mtr_rscheduler_eval(s: *const mtr_rscheduler, track: u32, frame: u32, value_bits: *mut u64) -> i32;
+    pub fn mtr_rarchive_parse(data: *const c_void, len: usize, out: *mut mtr_rarchive_view) -> i32;
+    pub fn mtr_rarchive_info(a: *const mtr_rarchive_view, i: u32, out: *mut mtr_resource_info) -> i32;
+    pub fn mtr_rarchive_find(a: *const mtr_rarchive_view, path: *const c_char, dti_hash: u32) -> i32;
+    pub fn mtr_rarchive_extract(a: *const mtr_rarchive_view, i: u32, out: *mut c_void, cap: usize, out_len: *mut usize) -> i32;
     pub fn mtr_model_create_from_files(dev: *mut mtr_device, model: *const mtr_rmodel_view, sh: *const mtr_rshader2, mat: *const mtr_rmaterial,
                                        textures: *const *mut mtr_texture, ntextures: usize, out: *mut *mut mtr_model) -> i32;
 }

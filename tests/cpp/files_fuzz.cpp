@@ -1,7 +1,7 @@
 // AddressSanitizer / UBSan run of the resource-file parsers (host build only: GPU sanitizers are not available).
 // Compiles csrc/mtr_files.cpp directly, with stand-ins for the few entry points of mtr.h it calls, and feeds it
 // deterministic mutations of the valid files named on the command line.
-// usage: files_fuzz <iterations> model.mod shader.mfx material.mrl texture.tex schedule.sdl
+// usage: files_fuzz <iterations> model.mod shader.mfx material.mrl texture.tex schedule.sdl archive.arc
 #include "../../mt_renderer_amd/csrc/mtr_files.cpp"
 
 #include <cstdlib>
@@ -60,16 +60,16 @@ static std::vector<uint8_t> mutate(std::vector<uint8_t> a) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 7) return 64;
+    if (argc != 8) return 64;
     const long iters = strtol(argv[1], nullptr, 10);
-    const std::vector<uint8_t> good[5] = {slurp(argv[2]), slurp(argv[3]), slurp(argv[4]), slurp(argv[5]), slurp(argv[6])};
+    const std::vector<uint8_t> good[6] = {slurp(argv[2]), slurp(argv[3]), slurp(argv[4]), slurp(argv[5]), slurp(argv[6]), slurp(argv[7])};
     mtr_rshader2* sh_ok = nullptr;
     if (mtr_rshader2_parse(good[1].data(), good[1].size(), &sh_ok)) return 3;
     long ok = 0, err = 0;
     for (long it = 0; it < iters; it++) {
-        const int which = (int)(rnd() % 5);
-        const std::vector<uint8_t> b = it < 5 ? good[it] : mutate(good[which]);
-        const int w = it < 5 ? (int)it : which;
+        const int which = (int)(rnd() % 6);
+        const std::vector<uint8_t> b = it < 6 ? good[it] : mutate(good[which]);
+        const int w = it < 6 ? (int)it : which;
         int32_t rc = 0;
         if (w == 0) {
             mtr_rmodel_view v;
@@ -117,6 +117,22 @@ int main(int argc, char** argv) {
             mtr_rtexture_view v;
             rc = mtr_rtexture_parse(b.data(), b.size(), &v);
             if (!rc && v.data_len) { volatile uint8_t s = v.data[0] ^ v.data[v.data_len - 1]; (void)s; }
+        } else if (w == 5) {
+            mtr_rarchive_view v;
+            rc = mtr_rarchive_parse(b.data(), b.size(), &v);
+            if (!rc) {
+                std::vector<uint8_t> out;
+                for (uint32_t i = 0; i < v.num_resources; i++) {
+                    mtr_resource_info ri;
+                    mtr_rarchive_info(&v, i, &ri);
+                    mtr_rarchive_find(&v, ri.path, ri.dti_hash);
+                    if (ri.size_uncompressed <= (1u << 22)) {
+                        out.resize(ri.size_uncompressed ? ri.size_uncompressed : 1);
+                        size_t n;
+                        mtr_rarchive_extract(&v, i, out.data(), ri.size_uncompressed, &n);
+                    }
+                }
+            }
         } else {
             mtr_rscheduler* sc = nullptr;
             rc = mtr_rscheduler_parse(b.data(), b.size(), &sc);
@@ -136,7 +152,7 @@ int main(int argc, char** argv) {
                 mtr_rscheduler_destroy(sc);
             }
         }
-        if (it < 5 && rc) { std::fprintf(stderr, "valid file %ld rejected: %s\n", it, mtr_files_last_error()); return 4; }
+        if (it < 6 && rc) { std::fprintf(stderr, "valid file %ld rejected: %s\n", it, mtr_files_last_error()); return 4; }
         (rc ? err : ok)++;
     }
     mtr_rshader2_destroy(sh_ok);

@@ -208,6 +208,21 @@ def files_from_model_data(md: scene.ModelData, texture_paths: Optional[Sequence[
     return rmodel, rshader2, rmaterial, rtextures
 
 
+# ------------------------------------------------------------------------------------------------ rArchive
+def write_rarchive(resources: Sequence[Tuple[str, int, bytes]], quality: int = 2, version: int = 7, magic: bytes = b"ARC\0",
+                   lie_about_size: int = 0) -> bytes:
+    """resources: (path, class hash, data).  Layout of ArchiveWriter::save (src/rarchive.rs:215-290): header, table of
+    0x90-byte entries, then the zlib streams back to back."""
+    import zlib
+    blobs = [zlib.compress(d, 6) for (_, _, d) in resources]
+    off = 8 + 0x90 * len(resources)
+    out = bytearray(magic + struct.pack("<HH", version, len(resources)))
+    for (path, dti, data), blob in zip(resources, blobs):
+        out += path.encode().ljust(128, b"\0")[:128] + struct.pack("<IIII", dti, len(blob), ((len(data) + lie_about_size) & 0x1FFFFFFF) | (quality << 29), off)
+        off += len(blob)
+    return bytes(out + b"".join(blobs))
+
+
 # ---------------------------------------------------------------------------------------------- rScheduler
 def write_rscheduler(tracks: Sequence[dict], version: int = 0x16, magic: bytes = b"SDL\0") -> bytes:
     """tracks: dicts {type, prop, name, [field_10], keys=[(frame, mode, value)]}; value: bool / int / float, or for

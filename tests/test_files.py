@@ -29,7 +29,7 @@ def test_struct_sizes_match_the_reference_size_tests():
                 TextureHeader=0x10, Shader2Header=0x20, RawShader2Object=0x28, RawShader2InputElement=0x10,
                 RawShader2InputLayout=16, RawShader2Struct=16, RawShader2Variable=0x30, RawShader2CBuffer=24,
                 MaterialHeader=0x28, RawTextureInfo=0x98, RawMaterialInfo=0x48, RawMaterialState=0x18, SchedulerTrack=0x30,
-                SchedulerHeader=0x20)
+                SchedulerHeader=0x20, ArchiveHeader=8, RawResourceInfo=0x90)
     for k, v in want.items():
         assert files.struct_size(k) == v, k
     assert api.lib.mtr_file_struct_size(99) == 0
@@ -255,6 +255,37 @@ def test_cpp_mirror_reads_the_same_files(tmp_path):
     assert r.returncode == 2 and "rModel" in r.stderr
 
 
+def test_rarchive_table_lookup_and_inflate():
+    md = _model()
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+    h = lambda name: mt_files.crc32_mt(name.encode()) & 0x7FFFFFFF
+    res = [("chr\\pl\\pl0000", h("rModel"), rmodel), ("chr\\pl\\pl0000", h("rMaterial"), rmaterial),
+           ("model\\tex\\t0_BM", h("rTexture"), rtextures[0]), ("empty", h("rTexture"), b"")]
+    arc = mt_files.write_rarchive(res)
+    af = files.ArchiveFile(arc)
+    infos = af.resource_infos()
+    assert [i["path"] for i in infos] == [r[0] for r in res] and [i["dti_hash"] for i in infos] == [r[1] for r in res]
+    assert [i["size_uncompressed"] for i in infos] == [len(r[2]) for r in res] and all(i["quality"] == 2 for i in infos)
+    for i, r in enumerate(res):
+        assert af.extract(i) == r[2]
+    # same path, two classes: the class hash picks (src/rarchive.rs:150-153); '/' is accepted for the separator
+    assert af.get_resource("chr/pl/pl0000", h("rMaterial")) == rmaterial and af.get_resource("chr\\pl\\pl0000", h("rModel")) == rmodel
+    assert af.get_resource("chr/pl/pl0000", h("rTexture")) is None and af.get_resource("nope", h("rModel")) is None
+    # and the extracted bytes parse: archive -> rModel
+    assert files.ModelFile(af.get_resource("chr/pl/pl0000", h("rModel"))).v.primitive_num == md.nprims
+    for bad in (mt_files.write_rarchive(res, magic=b"CRA\0"), mt_files.write_rarchive(res, version=8), arc[:8 + 0x90 * 2]):
+        with pytest.raises(api.MtrError):
+            files.ArchiveFile(bad)
+    with pytest.raises(api.MtrError):  # assert_eq!(num_decompressed_bytes, size_uncompressed), src/rarchive.rs:173
+        files.ArchiveFile(mt_files.write_rarchive(res, lie_about_size=5)).extract(0)
+    with pytest.raises(api.MtrError):  # a stream cut short
+        files.ArchiveFile(arc[:-3]).extract(3)
+    corrupt = bytearray(arc)
+    corrupt[8 + 0x90 * 4 + 20] ^= 0xFF  # inside the first zlib stream
+    with pytest.raises(api.MtrError):
+        files.ArchiveFile(bytes(corrupt)).extract(0)
+
+
 def test_parsers_survive_mutated_files():
     """Robustness: random byte flips, field overwrites with huge values and truncations of valid files must end in a
     normal return or an MtrError -- never a crash (every offset and count read from a file is bounds-checked).  A
@@ -338,13 +369,14 @@ def test_parsers_under_address_sanitizer(tmp_path):
                                      dict(type=6, prop=files.PROP_U32, name="i", keys=[(0, 0, 3)]),
                                      dict(type=13, prop=2, name="r", keys=[(0, 0, (5, "a\\b")), (1, 0, None)])])
     paths = []
-    for name, data in (("m.mod", rmodel_j), ("s.mfx", rshader2), ("m.mrl", rmaterial), ("t.tex", rtextures[0]), ("s.sdl", sdl)):
+    arc = mt_files.write_rarchive([("a\\b", 1, rmodel), ("a\\c", 2, bytes(range(256)) * 9), ("e", 3, b"")])
+    for name, data in (("m.mod", rmodel_j), ("s.mfx", rshader2), ("m.mrl", rmaterial), ("t.tex", rtextures[0]), ("s.sdl", sdl), ("a.arc", arc)):
         p = tmp_path / name
         p.write_bytes(data)
         paths.append(str(p))
     exe = str(tmp_path / "files_fuzz")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "files_fuzz.cpp"), "-o", exe])
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "files_fuzz.cpp"), "-o", exe, "-lz"])
     r = subprocess.run([exe, "30000"] + paths, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     ok, err = [int(t.split("=")[1]) for t in r.stdout.split()]

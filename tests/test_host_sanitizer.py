@@ -17,7 +17,7 @@ def test_host_api_under_address_sanitizer(tmp_path):
     exe = str(tmp_path / "host_fuzz")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            "-I", os.path.join(ROOT, "tests", "cpp", "hip_stub"), "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "host_fuzz.cpp"), "-o", exe])
+                           os.path.join(ROOT, "tests", "cpp", "host_fuzz.cpp"), "-o", exe, "-lz"])
     r = subprocess.run([exe, "6000"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
     created, rejected = [int(t.split("=")[1]) for t in r.stdout.split()]
