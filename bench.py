@@ -54,6 +54,11 @@ def main():
     ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with an unsharded render")
     args = ap.parse_args()
 
+    # N > 1: more hardware queues than ROCm's default 4, so that the exchange (public stream + RCCL's stream) does not
+    # share a queue with the library's three render streams; read by the HIP runtime when it starts, i.e. set it first
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,6 +97,11 @@ def main():
 
     # N > 1: each rank renders bins (bin % N == rank), packs them bin-major (csrc/k_shard.hip), one RCCL
     # all-gather over xGMI exchanges W*H*4/N bytes per rank, one unpack kernel rebuilds the linear frame
+    # The exchange of a frame is pack -> all-gather -> unpack on the device's public stream (which the library makes wait
+    # for each frame), while later frames render on the library's internal streams.  That only overlaps if the runtime
+    # gives those streams separate hardware queues: with ROCm's default of 4 the exchange shared a queue with the
+    # render streams and a frame took 0.089 ms instead of 0.057 (tools/probe/nccl_one_rank.py), hence
+    # GPU_MAX_HW_QUEUES=8 above.  Rotating several exchange streams was measured too and is worse (more queues to share).
     shard = gathered = final = None
     if world > 1:
         nbytes = int(api.lib.mtr_shard_bytes(W, H, world))

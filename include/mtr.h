@@ -170,6 +170,13 @@ size_t mtr_shard_bytes(uint32_t width, uint32_t height, uint32_t world);
 int32_t mtr_frame_pack_color_shard(mtr_frame *frame, void *dst_dev, size_t dst_bytes);
 int32_t mtr_device_unpack_color_shards(mtr_device *dev, const void *gathered_dev, uint32_t world,
                                        uint32_t width, uint32_t height, void *dst_dev);
+/* the same two steps on a caller-chosen hipStream_t instead of the device's public stream (the pack waits, on that
+ * stream, for the frame's completion).  One in-order stream makes the exchange chain of frame k+1 (pack -> all-gather
+ * -> unpack, with a cross-stream hand-over before and after the collective) wait for that of frame k; a host that
+ * rotates a few exchange streams, each with its own send / receive buffers, overlaps them (bench.py). */
+int32_t mtr_frame_pack_color_shard_on_stream(mtr_frame *frame, void *dst_dev, size_t dst_bytes, void *hip_stream);
+int32_t mtr_device_unpack_color_shards_on_stream(mtr_device *dev, const void *gathered_dev, uint32_t world,
+                                                 uint32_t width, uint32_t height, void *dst_dev, void *hip_stream);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
 /* tuning / test hook: per-bin queue sizes of the frame just rendered (valid until the next frame is submitted on

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "mtr_frame_depth_devptr", "mtr_frame_get_stats", "mtr_frame_get_timings", "mtr_frame_destroy",
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
+    "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
 ]
 
 
@@ -117,6 +118,8 @@ def _load() -> C.CDLL:
         "mtr_shard_bytes": (sz, [u32, u32, u32]),
         "mtr_frame_pack_color_shard": (i32, [vp, vp, sz]),
         "mtr_device_unpack_color_shards": (i32, [vp, vp, u32, u32, u32, vp]),
+        "mtr_frame_pack_color_shard_on_stream": (i32, [vp, vp, sz, vp]),
+        "mtr_device_unpack_color_shards_on_stream": (i32, [vp, vp, u32, u32, u32, vp, vp]),
         "mtr_frame_read_bin_counts": (i32, [vp, vp, vp, sz]),
         "mtr_device_set_tile_mode": (i32, [vp, i32]),
         "mtr_device_set_binning": (i32, [vp, i32, u32]),
@@ -159,10 +162,16 @@ class Device:
         if rc:
             raise MtrError(rc, (lib.mtr_last_error(self._h) or b"").decode())
 
-    def unpack_color_shards(self, gathered_devptr: int, world: int, width: int, height: int, dst_devptr: int):
-        """gathered [rank][k][16][16] RGBA8 blocks (device) -> linear RGBA8 framebuffer (device)."""
-        self.check(lib.mtr_device_unpack_color_shards(self._h, C.c_void_p(gathered_devptr), world, width, height,
-                                                      C.c_void_p(dst_devptr)))
+    def unpack_color_shards(self, gathered_devptr: int, world: int, width: int, height: int, dst_devptr: int,
+                            stream: Optional[int] = None):
+        """gathered [rank][k][16][16] RGBA8 blocks (device) -> linear RGBA8 framebuffer (device); on the device's public
+        stream, or on `stream` (a hipStream_t handle)."""
+        if stream is None:
+            self.check(lib.mtr_device_unpack_color_shards(self._h, C.c_void_p(gathered_devptr), world, width, height,
+                                                          C.c_void_p(dst_devptr)))
+        else:
+            self.check(lib.mtr_device_unpack_color_shards_on_stream(self._h, C.c_void_p(gathered_devptr), world, width, height,
+                                                                    C.c_void_p(dst_devptr), C.c_void_p(stream)))
 
     def set_tile_mode(self, mode: int):
         """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""
@@ -356,9 +365,13 @@ class Frame:
         self.dev.check(lib.mtr_frame_read_depth(self._h, _p(out), out.size))
         return out
 
-    def pack_color_shard(self, dst_devptr: int, dst_bytes: int):
-        """this rank's bins, bin-major, into the all-gather send buffer (device pointer)."""
-        self.dev.check(lib.mtr_frame_pack_color_shard(self._h, C.c_void_p(dst_devptr), dst_bytes))
+    def pack_color_shard(self, dst_devptr: int, dst_bytes: int, stream: Optional[int] = None):
+        """this rank's bins, bin-major, into the all-gather send buffer (device pointer); on the device's public stream,
+        or on `stream` (a hipStream_t handle; the pack then waits there for this frame's completion)."""
+        if stream is None:
+            self.dev.check(lib.mtr_frame_pack_color_shard(self._h, C.c_void_p(dst_devptr), dst_bytes))
+        else:
+            self.dev.check(lib.mtr_frame_pack_color_shard_on_stream(self._h, C.c_void_p(dst_devptr), dst_bytes, C.c_void_p(stream)))
 
     def color_devptr(self) -> int:
         return int(lib.mtr_frame_color_devptr(self._h) or 0)

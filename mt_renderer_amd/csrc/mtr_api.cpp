@@ -1129,27 +1129,48 @@ size_t mtr_shard_bytes(uint32_t w, uint32_t h, uint32_t world) {
     return (nbins + world - 1) / world * (MTR_BIN * MTR_BIN * 4);
 }
 
-int32_t mtr_frame_pack_color_shard(mtr_frame* f, void* dst_dev, size_t dst_bytes) {
+static int32_t pack_shard_on(mtr_frame* f, void* dst_dev, size_t dst_bytes, hipStream_t s, bool wait_frame) {
     if (!f || !dst_dev) return MTR_E_INVALID;
     mtr_device* d = f->dev;
     if (!f->submitted) return fail(d, MTR_E_INVALID, "frame not submitted");
     if (dst_bytes < mtr_shard_bytes(f->w, f->h, f->shard_world)) return fail(d, MTR_E_INVALID, "shard buffer too small");
     int32_t rc = set_device(d);
     if (rc) return rc;
-    mtr_launch_pack_shard(f->fb.color, static_cast<uint8_t*>(dst_dev), f->w, f->h, f->shard_rank, f->shard_world, d->stream);
+    if (wait_frame) HIPCHK(d, hipStreamWaitEvent(s, f->fb.done, 0));  // the public stream already waits for every frame
+    mtr_launch_pack_shard(f->fb.color, static_cast<uint8_t*>(dst_dev), f->w, f->h, f->shard_rank, f->shard_world, s);
+    HIPCHK(d, hipGetLastError());
+    // the colour buffer now has a reader after the tile kernel: whoever recycles it (the frame may be destroyed at
+    // once) must wait for the pack too, so the buffer's completion event moves behind it
+    HIPCHK(d, hipEventRecord(f->fb.done, s));
+    return MTR_OK;
+}
+
+int32_t mtr_frame_pack_color_shard(mtr_frame* f, void* dst_dev, size_t dst_bytes) {
+    return pack_shard_on(f, dst_dev, dst_bytes, f ? f->dev->stream : nullptr, false);
+}
+
+int32_t mtr_frame_pack_color_shard_on_stream(mtr_frame* f, void* dst_dev, size_t dst_bytes, void* hip_stream) {
+    return pack_shard_on(f, dst_dev, dst_bytes, reinterpret_cast<hipStream_t>(hip_stream), true);
+}
+
+static int32_t unpack_shards_on(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h, void* dst_dev, hipStream_t s) {
+    if (!d || !gathered_dev || !dst_dev) return MTR_E_INVALID;
+    if (world == 0 || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad unpack arguments");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    mtr_launch_unpack_shards(static_cast<const uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev), w, h, world, s);
     HIPCHK(d, hipGetLastError());
     return MTR_OK;
 }
 
 int32_t mtr_device_unpack_color_shards(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h,
                                        void* dst_dev) {
-    if (!d || !gathered_dev || !dst_dev) return MTR_E_INVALID;
-    if (world == 0 || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad unpack arguments");
-    int32_t rc = set_device(d);
-    if (rc) return rc;
-    mtr_launch_unpack_shards(static_cast<const uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev), w, h, world, d->stream);
-    HIPCHK(d, hipGetLastError());
-    return MTR_OK;
+    return unpack_shards_on(d, gathered_dev, world, w, h, dst_dev, d ? d->stream : nullptr);
+}
+
+int32_t mtr_device_unpack_color_shards_on_stream(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h,
+                                                 void* dst_dev, void* hip_stream) {
+    return unpack_shards_on(d, gathered_dev, world, w, h, dst_dev, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 int32_t mtr_frame_get_stats(mtr_frame* f, mtr_frame_stats* out) {

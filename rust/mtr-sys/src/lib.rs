@@ -97,6 +97,9 @@ extern "C" {
     pub fn mtr_frame_pack_color_shard(frame: *mut mtr_frame, dst_dev: *mut c_void, dst_bytes: usize) -> i32;
     pub fn mtr_device_unpack_color_shards(dev: *mut mtr_device, gathered_dev: *const c_void, world: u32, width: u32,
                                           height: u32, dst_dev: *mut c_void) -> i32;
+    pub fn mtr_frame_pack_color_shard_on_stream(frame: *mut mtr_frame, dst_dev: *mut c_void, dst_bytes: usize, hip_stream: *mut c_void) -> i32;
+    pub fn mtr_device_unpack_color_shards_on_stream(dev: *mut mtr_device, gathered_dev: *const c_void, world: u32, width: u32,
+                                                    height: u32, dst_dev: *mut c_void, hip_stream: *mut c_void) -> i32;
     pub fn mtr_frame_get_stats(frame: *mut mtr_frame, out: *mut mtr_frame_stats) -> i32;
     pub fn mtr_frame_get_timings(frame: *mut mtr_frame, ms: *mut f32) -> i32;
     pub fn mtr_frame_destroy(frame: *mut mtr_frame);
