@@ -56,7 +56,10 @@ def main():
 
     # N > 1: more hardware queues than ROCm's default 4, so that the exchange (public stream + RCCL's stream) does not
     # share a queue with the library's three render streams; read by the HIP runtime when it starts, i.e. set it first
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # MTR_BENCH_FORCE_DIST=1: run the N > 1 code path (process group, sharding calls, collective) with a world of one
+    # rank -- the only way to exercise it with the real nccl backend on a single GPU (tools/probe/bench_world1_nccl.sh)
+    force_dist = os.environ.get("MTR_BENCH_FORCE_DIST") == "1"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or force_dist:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import numpy as np
@@ -66,6 +69,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharded = world > 1 or force_dist
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -75,7 +79,7 @@ def main():
     backend = os.environ.get("MTR_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
@@ -103,24 +107,70 @@ def main():
     # render streams and a frame took 0.089 ms instead of 0.057 (tools/probe/nccl_one_rank.py), hence
     # GPU_MAX_HW_QUEUES=8 above.  Rotating several exchange streams was measured too and is worse (more queues to share).
     shard = gathered = final = None
-    if world > 1:
+    rc = None  # direct RCCL communicator (mt_renderer_amd/rccl.py), or None: torch.distributed's collective
+    if sharded:
         nbytes = int(api.lib.mtr_shard_bytes(W, H, world))
         shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         gathered = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
         final = torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")
+        if backend == "nccl" and os.environ.get("MTR_BENCH_TORCH_COLLECTIVE") != "1":
+            # ncclAllGather called straight from ctypes: ~3 us of host time per frame instead of ~20-30 us for
+            # dist.all_gather_into_tensor, which matters once a rank's share of the frame is below 30 us of GPU time.
+            # Every rank must take the same path: agree on it with a MIN all-reduce after each step that can fail.
+            def all_ok(ok):
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+            try:
+                from mt_renderer_amd import rccl
+                rc = rccl.Rccl()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] direct RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
+                rc = None
+            if all_ok(rc is not None):
+                uid = None
+                if rank == 0:
+                    try:
+                        uid = rc.unique_id()
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[rank 0] ncclGetUniqueId failed ({e}); using torch.distributed", file=sys.stderr)
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                ok = False
+                if box[0] is not None:
+                    import threading
+                    # ncclCommInitRank is a blocking collective: if it cannot complete, end the run instead of hanging
+                    guard = threading.Timer(180.0, lambda: (print(f"[rank {rank}] ncclCommInitRank did not return in 180 s",
+                                                                  file=sys.stderr, flush=True), os._exit(5)))
+                    guard.daemon = True
+                    guard.start()
+                    try:
+                        rc.init(box[0], world, rank)
+                        ok = True
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed", file=sys.stderr)
+                    guard.cancel()
+                if not all_ok(ok):
+                    rc = None
+            else:
+                rc = None
 
     def one_frame(check=False):
         fr = api.Frame(dev, W, H)
-        if world > 1:
+        if sharded:
             fr.set_shard(rank, world)
         model.render(fr, M)
         fr.submit()
         if check:
             fr.wait()  # grows the bin queues if needed and validates device flags
-        if world > 1:
+        if sharded:
             fr.pack_color_shard(shard.data_ptr(), shard.numel())
+            if rc is not None:
+                rc.all_gather_u8(shard.data_ptr(), gathered.data_ptr(), shard.numel(), stream.cuda_stream)
             with torch.cuda.stream(stream):
-                if backend == "nccl":
+                if rc is not None:
+                    pass
+                elif backend == "nccl":
                     dist.all_gather_into_tensor(gathered, shard)
                 else:  # rehearsal: host-staged gather
                     stream.synchronize()
@@ -132,7 +182,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -140,7 +190,7 @@ def main():
     # Device warm-up, untimed and independent of --warmup: the GPU's power management raises its clocks some 40 ms
     # after sustained load begins (one ~35 ms stall, then 52 us per frame instead of 58: tools/probe/hiccup.py), so a
     # short run would time the transition instead of the steady state.  0.3 s of the same frames first.
-    if world > 1:
+    if sharded:
         for _ in range(3000 if backend == "nccl" else 20):  # a fixed count: every rank must make the same number of collective calls
             one_frame()
     else:
@@ -156,11 +206,11 @@ def main():
         one_frame()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    if args.verify and world > 1:
+    if args.verify and sharded:
         fr = api.Frame(dev, W, H)
         model.render(fr, M)
         fr.end()
@@ -197,7 +247,7 @@ def main():
 
     for _ in range(nprof):
         fr = api.Frame(dev, W, H)
-        if world > 1:
+        if sharded:
             fr.set_shard(rank, world)
         model.render(fr, M)
         fr.submit()
@@ -209,7 +259,7 @@ def main():
     stage_ms_serial = {k: 0.0 for k in api.STAGE_NAMES}
     for _ in range(10):
         fr = api.Frame(dev, W, H)
-        if world > 1:
+        if sharded:
             fr.set_shard(rank, world)
         model.render(fr, M)
         fr.end()
@@ -260,13 +310,17 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
                                    "64-bone palette, debug-id shader, %dx%d" % (W, H),
-                       "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if world > 1 else "none"},
+                       "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if sharded else "none",
+                       "collective": ("ncclAllGather (ctypes)" if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
             "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
     model.close()
     dev.close()
-    if world > 1:
+    if sharded:
+        if rc is not None:
+            torch.cuda.synchronize()
+            rc.close()
         dist.destroy_process_group()
 
 

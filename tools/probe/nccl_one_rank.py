@@ -30,6 +30,13 @@ shards = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(N
 gathereds = [torch.empty(nbytes * world, dtype=torch.uint8, device="cuda") for _ in range(NX)]
 shard, gathered = shards[0], gathereds[0]
 count = [0]
+rc = None
+if MODE == "direct":
+    from mt_renderer_amd import rccl
+    rc = rccl.Rccl()
+    box = [rc.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    rc.init(box[0], world, rank)
 
 def one_frame():
     fr = api.Frame(dev, W, H)
@@ -46,6 +53,10 @@ def one_frame():
         with torch.cuda.stream(xstreams[x]):
             gathereds[x].copy_(shards[x], non_blocking=True)
         dev.unpack_color_shards(gathereds[x].data_ptr(), world, W, H, final.data_ptr(), stream=xstreams[x].cuda_stream)
+    elif MODE == "direct":  # ncclAllGather through ctypes on the public stream
+        fr.pack_color_shard(shards[0].data_ptr(), nbytes)
+        rc.all_gather_u8(shards[0].data_ptr(), gathereds[0].data_ptr(), nbytes, stream.cuda_stream)
+        dev.unpack_color_shards(gathereds[0].data_ptr(), world, W, H, final.data_ptr())
     elif NX == 1:
         fr.pack_color_shard(shards[0].data_ptr(), nbytes)
         with torch.cuda.stream(stream):
