@@ -593,3 +593,26 @@ def test_dynamic_instances_between_frames_in_flight(gpu_device):
             assert_same(got, render_oracle(w, h, [dict(md=md, vp=vp, model_mats=mats, palettes=pals)]), f"dynamic instances, frame {k}")
     finally:
         m.close()
+
+
+def test_fragment_lists_small_translucent_triangles_odd_viewport(gpu_device):
+    """The ordered kernel's fragment-list path: a finely tessellated skinned mesh with a TRANSLUCENT texture (thousands of
+    2-10 pixel triangles, several layers deep where the capsule's back shows through... culled, so 1-2 layers), drawn
+    twice with different transforms so fragments of two draws interleave per pixel, plus overlay cubes (constant
+    colour, no blend) in the same frame, on a 203x117 target whose last bins are partial."""
+    from mt_renderer_amd import api
+    w, h = 203, 117
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, size=(32, 32, 4), dtype=np.uint8)
+    img[..., 3] = rng.integers(30, 230, size=(32, 32))
+    tex = scene.TextureData(32, 32, scene.TEX_RGBA8, img.tobytes())
+    md = scene.mesh50k(textured=True, textures=[tex], rows=40, cols=64)
+    pal = scene.bone_palette()
+    M1 = scene.to_f32_colmajor(scene.headline_transform(w, h))
+    M2 = scene.to_f32_colmajor(scene.headline_transform(w, h) @ scene.mat_rot_y(0.4) @ scene.mat_translate(0.1, 0.05, 0.0))
+    cubes = np.stack([scene.to_f32_colmajor(scene.mat_translate(-5.0 + 0.1 * i, 0.05 * i, -1.3) @ scene.mat_scale(0.05, 0.05, 0.05)) for i in range(4)])
+    vp = scene.to_f32_colmajor(scene.reference_view_proj(w, h))
+    draws = [dict(md=md, M=M1, palette=pal), dict(md=md, overlay=cubes, vp=vp), dict(md=md, M=M2, palette=pal)]
+    g = render_gpu(gpu_device, w, h, draws)
+    assert g[2]["tile_kernel"] in (api.TILE_ORDERED, api.TILE_MIXED) and g[2]["tris_setup"] > 2000, g[2]
+    assert_same(g, render_oracle(w, h, draws), "fragment lists")
