@@ -8,8 +8,10 @@
 //      are sorted by submission key with an in-register bitonic network (wave shuffles),
 //   2. the concatenated, now fully ordered triangle list is set up 64 triangles at a time, one per
 //      lane, into LDS (integer edge equations relative to the bin origin, top-left bias folded in),
-//   3. per sub-tile the wave walks, in order, only the triangles whose bbox touches it (one ballot
-//      per sub-tile per pass), evaluating the three edge functions per lane, depth LessEqual
+//   3. a pass of small triangles is resolved through per-pixel FRAGMENT LISTS (the pairs flattened over the wave,
+//      each covered pair appends its triangle number to its pixel's list, lane = pixel then walks its list in
+//      submission order); any other pass: per sub-tile the wave walks, in order, only the triangles whose bbox
+//      touches it (one ballot per sub-tile per pass), evaluating the three edge functions per lane.  Either way: depth LessEqual
 //      (src/model.rs:255-261), the fragment shader (src/shaders/debug_ids.wgsl,
 //      src/shaders/textured.wgsl + sampler src/texture.rs:33-42) and the blend
 //      (src/model.rs:240-247) in submission order,

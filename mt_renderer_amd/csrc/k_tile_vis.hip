@@ -6,12 +6,13 @@
 // in submission order among equals.  So each pixel keeps one 64-bit key  (~bits(z) : order+1)  in
 // LDS and every fragment is an order-independent, fire-and-forget `ds_max_u64`:
 //   * 64 triangles are set up per pass, one per lane;
-//   * the (triangle, pixel-of-bbox) pairs of the triangles with <= 64 bbox pixels in the bin are FLATTENED over
-//     the wave: a pass costs sum(bbox pixels)/64 iterations whatever the mix of 1-pixel slivers and 8x8 patches
-//     (a lane = triangle walk ran max(bbox pixels) iterations at 29 % lane efficiency on the headline scene).
+//   * the (triangle, pixel-of-bbox) pairs of every i32-edge-class triangle are FLATTENED over the wave, in rounds of
+//     <= 4096 pairs: a pass costs sum(bbox pixels)/64 iterations whatever the mix of 1-pixel slivers and bin-filling
+//     triangles (a lane = triangle walk ran max(bbox pixels) iterations at 29 % lane efficiency on the headline scene).
 //     The pair -> triangle map needs no search: triangle t sets bit (prefix_t mod 64) of a 64-bit start mask per
 //     batch of 64 pairs (one ds_or_b64), and pair p's triangle is  #starts before its batch + popcount(mask bits
-//     <= p) - 1  (v_mbcnt).  Bigger triangles are rasterised by the whole wave, one at a time (v_readlane);
+//     <= p) - 1  (v_mbcnt).  Triangles over 64 px across (64-bit edge functions) are rasterised by the whole wave, one
+//     at a time (v_readlane);
 //   * shading is deferred: the winner's record is addressable from its order (chunk runs live at
 //     chunk * MTR_CHUNK_SLOTS), so the resolve does one colour lookup -- or one texture sample with the
 //     quad derivatives evaluated from the winner's plane equations exactly as SPEC.md section 7
