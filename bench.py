@@ -108,6 +108,8 @@ def main():
     # GPU_MAX_HW_QUEUES=8 above.  Rotating several exchange streams was measured too and is worse (more queues to share).
     shard = gathered = final = None
     rc = None  # direct RCCL communicator (mt_renderer_amd/rccl.py), or None: torch.distributed's collective
+    xthread = False  # the exchange runs on the library's exchange thread
+    xstream = None
     if sharded:
         nbytes = int(api.lib.mtr_shard_bytes(W, H, world))
         shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -154,6 +156,23 @@ def main():
                     rc = None
             else:
                 rc = None
+            # With the direct communicator the whole exchange of a frame (pack -> ncclAllGather -> unpack -> destroy) moves
+            # to the library's exchange thread (include/mtr.h: mtr_device_exchange_start): a rank's loop then costs the
+            # host ~31 us per frame instead of ~43 (tools/probe/exchange_thread.py), which is what bounds N > 1 on this
+            # frame.  MTR_BENCH_EXCHANGE_THREAD=0 keeps everything on one thread.
+            if rc is not None and os.environ.get("MTR_BENCH_EXCHANGE_THREAD") != "0":
+                xstream = torch.cuda.Stream()
+                started = False
+                try:
+                    dev.exchange_start(rc.allgather_addr, rc.comm_handle, rccl.ncclUint8, shard.data_ptr(), shard.numel(),
+                                       gathered.data_ptr(), final.data_ptr(), world, xstream.cuda_stream)
+                    started = True
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] exchange thread unavailable ({e}); exchanging on the render thread", file=sys.stderr)
+                if all_ok(started):
+                    xthread = True
+                elif started:
+                    dev.exchange_stop()
 
     def one_frame(check=False):
         fr = api.Frame(dev, W, H)
@@ -163,6 +182,9 @@ def main():
         fr.submit()
         if check:
             fr.wait()  # grows the bin queues if needed and validates device flags
+        if xthread:
+            fr.submit_exchange()  # the exchange thread packs, gathers, unpacks and destroys the frame
+            return
         if sharded:
             fr.pack_color_shard(shard.data_ptr(), shard.numel())
             if rc is not None:
@@ -181,6 +203,8 @@ def main():
         fr.close()
 
     def sync():
+        if xthread:
+            dev.exchange_drain()  # every handed-over frame has been issued
         torch.cuda.synchronize()
         if sharded:
             dist.barrier()
@@ -311,7 +335,7 @@ def main():
             "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
                                    "64-bone palette, debug-id shader, %dx%d" % (W, H),
                        "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if sharded else "none",
-                       "collective": ("ncclAllGather (ctypes)" if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
+                       "collective": (("ncclAllGather (exchange thread)" if xthread else "ncclAllGather (ctypes)") if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
             "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -177,6 +177,22 @@ int32_t mtr_device_unpack_color_shards(mtr_device *dev, const void *gathered_dev
 int32_t mtr_frame_pack_color_shard_on_stream(mtr_frame *frame, void *dst_dev, size_t dst_bytes, void *hip_stream);
 int32_t mtr_device_unpack_color_shards_on_stream(mtr_device *dev, const void *gathered_dev, uint32_t world,
                                                  uint32_t width, uint32_t height, void *dst_dev, void *hip_stream);
+/* The exchange of every sharded frame issued by a second host thread, owned by the device.  all-gather is the host's:
+ * `fn` has ncclAllGather's signature (sendbuff, recvbuff, sendcount, datatype, comm, stream) and is called with
+ * (send_dev, gathered_dev, send_bytes, dtype_u8, comm, hip_stream), so an RCCL host passes &ncclAllGather, its
+ * communicator and ncclUint8; the library links no collective library itself.  Per frame the thread runs, on hip_stream:
+ * pack (after the frame completes) -> fn -> unpack into dst_dev, then destroys the frame.
+ *   mtr_frame_submit_exchange: submits the frame if it was not yet, hands it to the thread and CONSUMES the handle
+ *       (blocks while 8 frames are waiting);   mtr_device_exchange_drain: returns once every handed-over frame has been
+ *       issued (not: finished on the GPU -- synchronise hip_stream for that) with the first error of the thread, if any;
+ *   mtr_device_exchange_stop: drain + join (also done by mtr_device_destroy).
+ * Frames of one device are still begun / drawn / submitted by ONE thread; only these calls cross threads. */
+typedef int (*mtr_allgather_fn)(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);
+int32_t mtr_device_exchange_start(mtr_device *dev, mtr_allgather_fn fn, void *comm, int dtype_u8, void *send_dev,
+                                  size_t send_bytes, void *gathered_dev, void *dst_dev, uint32_t world, void *hip_stream);
+int32_t mtr_frame_submit_exchange(mtr_frame *frame);
+int32_t mtr_device_exchange_drain(mtr_device *dev);
+int32_t mtr_device_exchange_stop(mtr_device *dev);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
 /* tuning / test hook: per-bin queue sizes of the frame just rendered (valid until the next frame is submitted on

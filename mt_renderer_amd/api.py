@@ -35,6 +35,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
+    "mtr_device_exchange_start", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
 
@@ -120,6 +121,10 @@ def _load() -> C.CDLL:
         "mtr_device_unpack_color_shards": (i32, [vp, vp, u32, u32, u32, vp]),
         "mtr_frame_pack_color_shard_on_stream": (i32, [vp, vp, sz, vp]),
         "mtr_device_unpack_color_shards_on_stream": (i32, [vp, vp, u32, u32, u32, vp, vp]),
+        "mtr_device_exchange_start": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, u32, vp]),
+        "mtr_frame_submit_exchange": (i32, [vp]),
+        "mtr_device_exchange_drain": (i32, [vp]),
+        "mtr_device_exchange_stop": (i32, [vp]),
         "mtr_frame_read_bin_counts": (i32, [vp, vp, vp, sz]),
         "mtr_device_set_tile_mode": (i32, [vp, i32]),
         "mtr_device_set_binning": (i32, [vp, i32, u32]),
@@ -172,6 +177,21 @@ class Device:
         else:
             self.check(lib.mtr_device_unpack_color_shards_on_stream(self._h, C.c_void_p(gathered_devptr), world, width, height,
                                                                     C.c_void_p(dst_devptr), C.c_void_p(stream)))
+
+    def exchange_start(self, allgather_fn_addr: int, comm: int, dtype_u8: int, send_devptr: int, send_bytes: int,
+                       gathered_devptr: int, dst_devptr: int, world: int, stream: int):
+        """start the device's exchange thread (include/mtr.h): per handed-over frame, on `stream`, pack -> all-gather
+        (a C function with ncclAllGather's signature, e.g. rccl.Rccl().allgather_addr) -> unpack into dst -> destroy."""
+        self.check(lib.mtr_device_exchange_start(self._h, C.c_void_p(allgather_fn_addr), C.c_void_p(comm), dtype_u8,
+                                                 C.c_void_p(send_devptr), send_bytes, C.c_void_p(gathered_devptr),
+                                                 C.c_void_p(dst_devptr), world, C.c_void_p(stream)))
+
+    def exchange_drain(self):
+        """returns once every frame handed to the exchange thread has been issued; raises its first error"""
+        self.check(lib.mtr_device_exchange_drain(self._h))
+
+    def exchange_stop(self):
+        self.check(lib.mtr_device_exchange_stop(self._h))
 
     def set_tile_mode(self, mode: int):
         """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""
@@ -348,6 +368,11 @@ class Frame:
 
     def submit(self):
         self.dev.check(lib.mtr_frame_submit(self._h))
+
+    def submit_exchange(self):
+        """submit (if not yet) and hand the frame to the device's exchange thread, which owns it from here on"""
+        self.dev.check(lib.mtr_frame_submit_exchange(self._h))
+        self._h = None
 
     def wait(self):
         self.dev.check(lib.mtr_frame_wait(self._h))

@@ -10,6 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -84,9 +89,35 @@ struct mtr_device {
     // two-pass queues and the bound is doubled for later frames
     bool direct_enabled = true;
     uint32_t qcap = 1024, scap = 128;
+    // parked colour / depth sets.  The one piece of device state a second host thread may touch: a frame can be packed
+    // (mtr_frame_pack_color_shard_on_stream) and destroyed on an exchange thread while the render thread begins others.
+    std::mutex pool_mu;
     std::vector<ColorDepth> free_fb;
     std::vector<std::pair<uint64_t, uint32_t>> fb_allocated;  // (w << 32 | h) -> colour / depth sets ever allocated
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
+    struct Exchange* xchg = nullptr;  // exchange thread of a sharded device (mtr_device_exchange_start)
+};
+
+// The exchange of a sharded frame (pack -> the host's all-gather -> unpack -> frame destroy) issued by a second host
+// thread: a rank's share of a small frame is ~30 us of GPU time, the render submission alone costs the host ~30 us, and
+// the three exchange calls another ~15 us -- on one thread they add, on two they overlap.
+struct Exchange {
+    mtr_allgather_fn fn = nullptr;
+    void* comm = nullptr;
+    int dtype_u8 = 0;
+    uint8_t *send = nullptr, *gathered = nullptr, *dst = nullptr;
+    size_t send_bytes = 0;
+    uint32_t world = 1;
+    hipStream_t stream = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_items, cv_idle;
+    std::deque<mtr_frame*> q;
+    std::atomic<uint32_t> pending{0};  // queued + being processed
+    bool stop = false;
+    int32_t err = MTR_OK;
+    std::string err_msg;
+    static constexpr size_t kDepth = 8;  // frames handed over and not yet issued
 };
 
 struct mtr_texture {
@@ -180,7 +211,10 @@ struct mtr_frame {
 
 namespace {
 
+std::mutex g_err_mu;  // two host threads (render + exchange) may fail at once
+
 int32_t fail(mtr_device* d, int32_t code, const std::string& msg) {
+    std::lock_guard<std::mutex> g(g_err_mu);
     if (d) d->err = msg; else g_create_error = msg;
     return code;
 }
@@ -323,6 +357,7 @@ int32_t mtr_device_create(int32_t hip_device, mtr_device** out) {
 
 void mtr_device_destroy(mtr_device* d) {
     if (!d) return;
+    (void)mtr_device_exchange_stop(d);
     (void)hipSetDevice(d->hip_dev);
     (void)hipStreamSynchronize(d->stream);
     for (Slot& sl : d->slots)
@@ -673,6 +708,7 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
     // destroys a frame per step would otherwise chain every frame to its predecessor)
     bool found = false;
     size_t same = 0, oldest = SIZE_MAX, ready = SIZE_MAX;
+    std::unique_lock<std::mutex> pool_lock(d->pool_mu);
     for (size_t i = 0; i < d->free_fb.size(); i++)
         if (d->free_fb[i].w == w && d->free_fb[i].h == h) {
             same++;
@@ -692,13 +728,23 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
         d->free_fb.erase(d->free_fb.begin() + (long)pick);
         found = true;
     }
+    if (!found) ++*total;
+    pool_lock.unlock();
     if (!found) {
         f->fb.w = w; f->fb.h = h;
-        if ((rc = dev_alloc(d, &f->fb.color, (size_t)w * h * 4))) return rc;
-        if ((rc = dev_alloc(d, &f->fb.depth, (size_t)w * h))) return rc;
-        if ((rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM))) return rc;
-        HIPCHK(d, hipEventCreateWithFlags(&f->fb.done, hipEventDisableTiming));
-        ++*total;
+        if (!(rc = dev_alloc(d, &f->fb.color, (size_t)w * h * 4)) && !(rc = dev_alloc(d, &f->fb.depth, (size_t)w * h)) &&
+            !(rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM)) &&
+            hipEventCreateWithFlags(&f->fb.done, hipEventDisableTiming) != hipSuccess)
+            rc = fail(d, MTR_E_HIP, "hipEventCreate failed");
+        if (rc) {  // give the partial set back
+            if (f->fb.color) (void)hipFree(f->fb.color);
+            if (f->fb.depth) (void)hipFree(f->fb.depth);
+            if (f->fb.counters) (void)hipFree(f->fb.counters);
+            std::lock_guard<std::mutex> g(d->pool_mu);
+            for (auto& e : d->fb_allocated)
+                if (e.first == (((uint64_t)w << 32) | h)) --e.second;
+            return rc;
+        }
     }
     *out = f.release();
     return MTR_OK;
@@ -712,7 +758,10 @@ void mtr_frame_destroy(mtr_frame* f) {
         for (auto& e : f->ev)
             if (e) (void)hipEventDestroy(e);
     // the buffers may still be written by this frame's kernels: whoever recycles them waits on fb.done
-    d->free_fb.push_back(f->fb);
+    {
+        std::lock_guard<std::mutex> g(d->pool_mu);
+        d->free_fb.push_back(f->fb);
+    }
     delete f;
 }
 
@@ -1239,6 +1288,124 @@ int32_t mtr_model_vertex_stage(mtr_model* m, size_t prim, const float M[16], flo
     (void)hipFree(d_clip);
     (void)hipFree(d_uv);
     return MTR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exchange thread
+// ---------------------------------------------------------------------------------------------
+static void exchange_main(mtr_device* d, Exchange* x) {
+    (void)hipSetDevice(d->hip_dev);
+    for (;;) {
+        mtr_frame* f = nullptr;
+        // a frame arrives every few tens of microseconds: poll briefly before sleeping on the condition variable
+        for (int spin = 0; spin < 20000 && !f; spin++) {
+            if (x->pending.load(std::memory_order_acquire)) {
+                std::lock_guard<std::mutex> g(x->mu);
+                if (!x->q.empty()) { f = x->q.front(); x->q.pop_front(); }
+            } else {
+                __builtin_ia32_pause();
+            }
+        }
+        if (!f) {
+            std::unique_lock<std::mutex> lk(x->mu);
+            x->cv_items.wait(lk, [&] { return x->stop || !x->q.empty(); });
+            if (x->q.empty()) return;  // stop requested and nothing left
+            f = x->q.front(); x->q.pop_front();
+        }
+        x->cv_items.notify_all();  // room in the queue
+        int32_t rc = x->err;
+        std::string msg;
+        if (rc == MTR_OK) {
+            rc = mtr_frame_pack_color_shard_on_stream(f, x->send, x->send_bytes, x->stream);
+            if (rc != MTR_OK) {
+                msg = d->err;
+            } else {
+                const int nrc = x->fn(x->send, x->gathered, x->send_bytes, x->dtype_u8, x->comm, x->stream);
+                if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
+            }
+            if (rc == MTR_OK) {
+                rc = mtr_device_unpack_color_shards_on_stream(d, x->gathered, x->world, f->w, f->h, x->dst, x->stream);
+                if (rc != MTR_OK) msg = d->err;
+            }
+        }
+        mtr_frame_destroy(f);
+        {
+            std::lock_guard<std::mutex> g(x->mu);
+            if (rc != MTR_OK && x->err == MTR_OK) { x->err = rc; x->err_msg = msg; }
+            x->pending.fetch_sub(1, std::memory_order_release);
+        }
+        x->cv_idle.notify_all();
+    }
+}
+
+int32_t mtr_device_exchange_start(mtr_device* d, mtr_allgather_fn fn, void* comm, int dtype_u8, void* send_dev, size_t send_bytes,
+                                  void* gathered_dev, void* dst_dev, uint32_t world, void* hip_stream) {
+    if (!d) return MTR_E_INVALID;
+    if (!fn || !send_dev || !gathered_dev || !dst_dev || world == 0 || !hip_stream)
+        return fail(d, MTR_E_INVALID, "bad exchange arguments");
+    if (d->xchg) return fail(d, MTR_E_INVALID, "exchange already started");
+    auto* x = new Exchange();
+    x->fn = fn; x->comm = comm; x->dtype_u8 = dtype_u8;
+    x->send = static_cast<uint8_t*>(send_dev); x->send_bytes = send_bytes;
+    x->gathered = static_cast<uint8_t*>(gathered_dev); x->dst = static_cast<uint8_t*>(dst_dev);
+    x->world = world; x->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    d->xchg = x;
+    x->th = std::thread(exchange_main, d, x);
+    return MTR_OK;
+}
+
+int32_t mtr_frame_submit_exchange(mtr_frame* f) {
+    if (!f) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    Exchange* x = d->xchg;
+    if (!x) return fail(d, MTR_E_INVALID, "no exchange thread (mtr_device_exchange_start)");
+    if (f->shard_world != x->world) return fail(d, MTR_E_INVALID, "frame shard world differs from the exchange's");
+    if (x->send_bytes < mtr_shard_bytes(f->w, f->h, x->world)) return fail(d, MTR_E_INVALID, "exchange send buffer too small");
+    if (!f->submitted) {
+        int32_t rc = mtr_frame_submit(f);
+        if (rc) return rc;
+    }
+    {
+        std::unique_lock<std::mutex> lk(x->mu);
+        x->cv_items.wait(lk, [&] { return x->q.size() < Exchange::kDepth; });
+        x->q.push_back(f);
+        x->pending.fetch_add(1, std::memory_order_release);
+    }
+    x->cv_items.notify_all();
+    return MTR_OK;
+}
+
+int32_t mtr_device_exchange_drain(mtr_device* d) {
+    if (!d) return MTR_E_INVALID;
+    Exchange* x = d->xchg;
+    if (!x) return MTR_OK;
+    std::unique_lock<std::mutex> lk(x->mu);
+    x->cv_idle.wait(lk, [&] { return x->pending.load(std::memory_order_acquire) == 0; });
+    if (x->err != MTR_OK) {
+        const int32_t rc = x->err;
+        const std::string msg = "exchange thread: " + x->err_msg;
+        x->err = MTR_OK;
+        lk.unlock();
+        return fail(d, rc, msg);
+    }
+    return MTR_OK;
+}
+
+int32_t mtr_device_exchange_stop(mtr_device* d) {
+    if (!d) return MTR_E_INVALID;
+    Exchange* x = d->xchg;
+    if (!x) return MTR_OK;
+    const int32_t rc = mtr_device_exchange_drain(d);
+    {
+        std::lock_guard<std::mutex> g(x->mu);
+        x->stop = true;
+    }
+    x->cv_items.notify_all();
+    x->th.join();
+    (void)hipStreamSynchronize(x->stream);
+    d->xchg = nullptr;
+    delete x;
+    return rc;
 }
 
 uint32_t mtr_crc32(const uint8_t* bytes, size_t len, uint32_t init) {

@@ -64,6 +64,15 @@ class Rccl:
         self._check(self.lib.ncclAllGather(C.c_void_p(send_devptr), C.c_void_p(recv_devptr), nbytes, ncclUint8, self.comm,
                                            C.c_void_p(stream)), "ncclAllGather")
 
+    @property
+    def allgather_addr(self) -> int:
+        """address of ncclAllGather, for a native caller (mtr_device_exchange_start)"""
+        return C.cast(self.lib.ncclAllGather, C.c_void_p).value
+
+    @property
+    def comm_handle(self) -> int:
+        return self.comm.value or 0
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)
