@@ -33,6 +33,13 @@ class Device {
     void unpack_color_shards(const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h, void* dst_dev) const {
         check(mtr_device_unpack_color_shards(h_, gathered_dev, world, w, h, dst_dev));
     }
+    // the exchange of sharded frames on a second host thread (mtr.h): fn = &ncclAllGather for an RCCL host
+    void exchange_start(mtr_allgather_fn fn, void* comm, int dtype_u8, void* send_dev, size_t send_bytes, void* gathered_dev,
+                        void* dst_dev, uint32_t world, void* hip_stream) const {
+        check(mtr_device_exchange_start(h_, fn, comm, dtype_u8, send_dev, send_bytes, gathered_dev, dst_dev, world, hip_stream));
+    }
+    void exchange_drain() const { check(mtr_device_exchange_drain(h_)); }
+    void exchange_stop() const { check(mtr_device_exchange_stop(h_)); }
     void check(int32_t rc) const {
         if (rc) throw Error(rc, mtr_last_error(h_));
     }
@@ -104,6 +111,11 @@ class Frame {
     // multi-GPU: render only the bins with (bin % world) == rank, then pack them for the all-gather
     void set_shard(uint32_t rank, uint32_t world) { dev_.check(mtr_frame_set_shard(h_, rank, world)); }
     void pack_color_shard(void* dst_dev, size_t dst_bytes) { dev_.check(mtr_frame_pack_color_shard(h_, dst_dev, dst_bytes)); }
+    // hands the frame to the device's exchange thread, which owns (and destroys) it from here on
+    void submit_exchange() {
+        dev_.check(mtr_frame_submit_exchange(h_));
+        h_ = nullptr;
+    }
     void* color_devptr() const { return mtr_frame_color_devptr(h_); }
     void* depth_devptr() const { return mtr_frame_depth_devptr(h_); }
     void read_color(void* rgba8, size_t len) { dev_.check(mtr_frame_read_color(h_, rgba8, len)); }

@@ -54,6 +54,9 @@ pub struct mtr_frame_stats {
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
 opaque!(mtr_device, mtr_texture, mtr_model, mtr_batch, mtr_frame);
 
+pub type mtr_allgather_fn = Option<unsafe extern "C" fn(send: *const c_void, recv: *mut c_void, count: usize, datatype: i32,
+                                                         comm: *mut c_void, stream: *mut c_void) -> i32>;
+
 extern "C" {
     pub fn mtr_abi_version() -> i32;
     pub fn mtr_device_create(hip_device: i32, out: *mut *mut mtr_device) -> i32;
@@ -100,6 +103,13 @@ extern "C" {
     pub fn mtr_frame_pack_color_shard_on_stream(frame: *mut mtr_frame, dst_dev: *mut c_void, dst_bytes: usize, hip_stream: *mut c_void) -> i32;
     pub fn mtr_device_unpack_color_shards_on_stream(dev: *mut mtr_device, gathered_dev: *const c_void, world: u32, width: u32,
                                                     height: u32, dst_dev: *mut c_void, hip_stream: *mut c_void) -> i32;
+    /// exchange thread (mtr.h): `fn_` has ncclAllGather's signature; `mtr_frame_submit_exchange` consumes the frame
+    pub fn mtr_device_exchange_start(dev: *mut mtr_device, fn_: mtr_allgather_fn, comm: *mut c_void, dtype_u8: i32,
+                                     send_dev: *mut c_void, send_bytes: usize, gathered_dev: *mut c_void, dst_dev: *mut c_void,
+                                     world: u32, hip_stream: *mut c_void) -> i32;
+    pub fn mtr_frame_submit_exchange(frame: *mut mtr_frame) -> i32;
+    pub fn mtr_device_exchange_drain(dev: *mut mtr_device) -> i32;
+    pub fn mtr_device_exchange_stop(dev: *mut mtr_device) -> i32;
     pub fn mtr_frame_get_stats(frame: *mut mtr_frame, out: *mut mtr_frame_stats) -> i32;
     pub fn mtr_frame_get_timings(frame: *mut mtr_frame, ms: *mut f32) -> i32;
     pub fn mtr_frame_destroy(frame: *mut mtr_frame);
