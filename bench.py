@@ -158,7 +158,7 @@ def main():
                 rc = None
             # With the direct communicator the whole exchange of a frame (pack -> ncclAllGather -> unpack -> destroy) moves
             # to the library's exchange thread (include/mtr.h: mtr_device_exchange_start): a rank's loop then costs the
-            # host ~31 us per frame instead of ~43 (tools/probe/exchange_thread.py), which is what bounds N > 1 on this
+            # host ~28-31 us per frame instead of ~43-51 (tools/probe/exchange_thread.py), which is what bounds N > 1 on this
             # frame.  MTR_BENCH_EXCHANGE_THREAD=0 keeps everything on one thread.
             if rc is not None and os.environ.get("MTR_BENCH_EXCHANGE_THREAD") != "0":
                 xstream = torch.cuda.Stream()
@@ -179,7 +179,8 @@ def main():
         if sharded:
             fr.set_shard(rank, world)
         model.render(fr, M)
-        fr.submit()
+        if check or not xthread:
+            fr.submit()
         if check:
             fr.wait()  # grows the bin queues if needed and validates device flags
         if xthread:

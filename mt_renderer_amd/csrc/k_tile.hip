@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     __shared__ uint32_t s_pm[TRI_PASS];         // pair prefix | magic(bbox width) << 12
     __shared__ uint8_t s_tmap[TRI_PASS];        // compacted index -> triangle of the pass
 
+    zero_next_counters(P);
     const uint32_t lane = threadIdx.x;
     const uint32_t nbx = P.fb.nbx, nbins = nbx * P.fb.nby;
     const uint32_t world = P.fb.shard_world ? P.fb.shard_world : 1u;

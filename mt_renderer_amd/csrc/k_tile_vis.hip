@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    zero_next_counters(P);
     uint32_t bin;
     if (!block_to_bin(P.fb, bin)) return;  // uniform over the workgroup, before any barrier
     const uint32_t nbx = P.fb.nbx;

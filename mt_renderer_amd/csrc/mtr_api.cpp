@@ -27,7 +27,12 @@ struct ColorDepth {
     uint32_t w, h;
     uint8_t* color;
     float* depth;
-    uint32_t* counters;
+    uint32_t* counters;  // two blocks of CTR_NUM words: a frame counts in block ctr_live and its tile kernel zeroes the other
+    uint32_t ctr_live = 0;
+    bool ctr_dirty = true;     // the live block must be zeroed by a fill before the next run (fresh memory, or a re-run)
+    bool next_zeroed = false;  // a tile kernel has been queued that zeroes the other block
+    uint32_t* live() const { return counters + (size_t)ctr_live * CTR_NUM; }
+    uint32_t* other() const { return counters + (size_t)(ctr_live ^ 1u) * CTR_NUM; }
     // recorded after the tile kernel of the last frame that rendered into these buffers; a frame that recycles
     // them (possibly on another internal stream) waits on it before its first write
     hipEvent_t done = nullptr;
@@ -207,6 +212,7 @@ struct mtr_frame {
     float ms[MTR_STAGE_COUNT] = {};
     int slot = 0;
     uint64_t min_entries = 0, min_segs = 0;  // queue sizes measured by a previous, overflowed attempt
+    bool for_exchange = false;  // submitted through mtr_frame_submit_exchange: no public-stream consumer
 };
 
 namespace {
@@ -727,13 +733,15 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
         f->fb = d->free_fb[pick];
         d->free_fb.erase(d->free_fb.begin() + (long)pick);
         found = true;
+        // the last frame on this set zeroed the other counter block in its tile kernel: count there
+        if (f->fb.next_zeroed) { f->fb.ctr_live ^= 1u; f->fb.next_zeroed = false; f->fb.ctr_dirty = false; }
     }
     if (!found) ++*total;
     pool_lock.unlock();
     if (!found) {
         f->fb.w = w; f->fb.h = h;
         if (!(rc = dev_alloc(d, &f->fb.color, (size_t)w * h * 4)) && !(rc = dev_alloc(d, &f->fb.depth, (size_t)w * h)) &&
-            !(rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM)) &&
+            !(rc = dev_alloc(d, &f->fb.counters, (size_t)CTR_NUM * 2)) &&
             hipEventCreateWithFlags(&f->fb.done, hipEventDisableTiming) != hipSuccess)
             rc = fail(d, MTR_E_HIP, "hipEventCreate failed");
         if (rc) {  // give the partial set back
@@ -990,7 +998,7 @@ static int32_t run_frame(mtr_frame* f) {
     FrameBuffers fb{};
     fb.rec_hdr = sl.rec_hdr; fb.rec_a = sl.rec_a; fb.rec_b = sl.rec_b; fb.chunk_info = sl.chunk_info;
     fb.bin_count = sl.bin_count; fb.bin_fill = sl.bin_fill; fb.bin_start = sl.bin_start; fb.seg_start = sl.seg_start;
-    fb.entries = sl.entries; fb.segs = sl.segs; fb.counters = f->fb.counters;
+    fb.entries = sl.entries; fb.segs = sl.segs; fb.counters = f->fb.live();
     fb.rec_cap = sl.rec_cap; fb.entry_cap = sl.entry_cap; fb.seg_cap = sl.seg_cap;
     fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
     fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
@@ -1009,7 +1017,8 @@ static int32_t run_frame(mtr_frame* f) {
     hipStream_t sg = sl.stream, st = sl.stream;
     // recycled colour / depth / counter buffers: their last frame may have run on another slot's stream
     if (f->fb.used) HIPCHK(d, hipStreamWaitEvent(sg, f->fb.done, 0));
-    HIPCHK(d, hipMemsetAsync(f->fb.counters, 0, CTR_NUM * sizeof(uint32_t), sg));
+    if (f->fb.ctr_dirty) HIPCHK(d, hipMemsetAsync(f->fb.live(), 0, CTR_NUM * sizeof(uint32_t), sg));
+    f->fb.ctr_dirty = true;  // a second run of this frame (queue overflow) starts from a fill again
     if (!fb.direct) {
         HIPCHK(d, hipMemsetAsync(sl.bin_count, 0, (size_t)(nbins + 1) * sizeof(unsigned long long), sg));
         sl.bin_fill_dirty = true;
@@ -1058,6 +1067,8 @@ static int32_t run_frame(mtr_frame* f) {
     for (const DMat& dm : mats) any_opaque = any_opaque || !dm.translucent;
     const bool mixed = !use_vis && d->tile_mode == MTR_TILE_AUTO && any_opaque;
     tp.bin_flag = sl.bin_flag; tp.mixed = mixed ? 1u : 0u;
+    tp.zero_next = f->fb.other();
+    f->fb.next_zeroed = true;
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
     if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
     if (!use_vis) mtr_launch_tile(tp, any_textured, st);
@@ -1066,7 +1077,7 @@ static int32_t run_frame(mtr_frame* f) {
     HIPCHK(d, hipEventRecord(ring, st));
     f->fb.used = true;
     // the device's public stream (read-backs, shard packing, the caller's own work) sees the framebuffer complete
-    HIPCHK(d, hipStreamWaitEvent(d->stream, f->fb.done, 0));
+    if (!f->for_exchange) HIPCHK(d, hipStreamWaitEvent(d->stream, f->fb.done, 0));
     HIPCHK(d, hipGetLastError());
     {
         const uint32_t tk = f->stats.tile_kernel;
@@ -1099,7 +1110,7 @@ int32_t mtr_frame_wait(mtr_frame* f) {
         uint32_t ctr[CTR_NUM];
         // wait for THIS frame only (the public stream also carries the completion of every later frame)
         HIPCHK(d, hipEventSynchronize(f->fb.done));
-        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.counters, sizeof ctr, hipMemcpyDeviceToHost, d->s_copy));
+        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.live(), sizeof ctr, hipMemcpyDeviceToHost, d->s_copy));
         HIPCHK(d, hipStreamSynchronize(d->s_copy));
         f->stats.tris_setup = 0;
         for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[MTR_CTR(CTR_REC, k)];
@@ -1362,8 +1373,9 @@ int32_t mtr_frame_submit_exchange(mtr_frame* f) {
     if (f->shard_world != x->world) return fail(d, MTR_E_INVALID, "frame shard world differs from the exchange's");
     if (x->send_bytes < mtr_shard_bytes(f->w, f->h, x->world)) return fail(d, MTR_E_INVALID, "exchange send buffer too small");
     if (!f->submitted) {
+        f->for_exchange = true;  // its only consumer is the exchange thread, which waits for the frame on its own stream
         int32_t rc = mtr_frame_submit(f);
-        if (rc) return rc;
+        if (rc) { f->for_exchange = false; return rc; }
     }
     {
         std::unique_lock<std::mutex> lk(x->mu);

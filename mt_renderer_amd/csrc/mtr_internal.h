@@ -159,6 +159,9 @@ struct TileParams {
     // flags the others in bin_flag[]; k_tile then renders the flagged bins in submission order
     uint8_t* bin_flag;
     uint32_t mixed;
+    // the counter block the NEXT frame on these framebuffers will use (CTR_NUM words), zeroed by this frame's tile
+    // kernel so that no fill has to be launched per frame; nullptr: nothing to zero
+    uint32_t* zero_next;
 };
 
 // launchers (defined in the .hip files, called from mtr_api.cpp)

@@ -5,6 +5,12 @@
 
 namespace mtr {
 
+// every workgroup of a tile kernel clears its slice of the counter block the next frame on these framebuffers will use
+__device__ __forceinline__ void zero_next_counters(const TileParams& P) {
+    if (!P.zero_next) return;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)CTR_NUM; i += gridDim.x * blockDim.x) P.zero_next[i] = 0u;
+}
+
 // byte / 255, bit-identical to the IEEE division SPEC.md spells, in three instructions instead of the ten of the
 // correctly rounded divide expansion: q0 = x * r, e = fma(-q0, 255, x), q = fma(e, r, q0), r = RN(1 / 255).  Verified
 // for all 256 bytes with exact rational arithmetic (tests/test_div_exact.py; the bare product x * r is wrong for 126
