@@ -22,3 +22,19 @@ def test_host_api_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
     created, rejected = [int(t.split("=")[1]) for t in r.stdout.split()]
     assert created > 1500 and rejected > 1500, r.stdout
+
+
+def test_exchange_thread_under_thread_sanitizer(tmp_path):
+    """render thread + the device's exchange thread over the stub runtime: 4000 frames begun, drawn, handed over, packed,
+    "gathered", unpacked and destroyed; ThreadSanitizer reports any unsynchronised access to shared host state (removing
+    the pool mutex from mtr_frame_destroy makes it fire)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "exchange_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-w",
+                           "-I", os.path.join(ROOT, "tests", "cpp", "hip_stub"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "exchange_tsan.cpp"), "-o", exe, "-lz", "-pthread"])
+    r = subprocess.run([exe, "4000"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
+    assert int(r.stdout.strip().split("=")[1]) > 2500
