@@ -1329,14 +1329,14 @@ static void exchange_main(mtr_device* d, Exchange* x) {
         if (rc == MTR_OK) {
             rc = mtr_frame_pack_color_shard_on_stream(f, x->send, x->send_bytes, x->stream);
             if (rc != MTR_OK) {
-                msg = d->err;
+                { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             } else {
                 const int nrc = x->fn(x->send, x->gathered, x->send_bytes, x->dtype_u8, x->comm, x->stream);
                 if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
             }
             if (rc == MTR_OK) {
                 rc = mtr_device_unpack_color_shards_on_stream(d, x->gathered, x->world, f->w, f->h, x->dst, x->stream);
-                if (rc != MTR_OK) msg = d->err;
+                if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             }
         }
         mtr_frame_destroy(f);
