@@ -183,7 +183,7 @@ int32_t mtr_device_unpack_color_shards_on_stream(mtr_device *dev, const void *ga
  * communicator and ncclUint8; the library links no collective library itself.  Per frame the thread runs, on hip_stream:
  * pack (after the frame completes) -> fn -> unpack into dst_dev, then destroys the frame.
  *   mtr_frame_submit_exchange: submits the frame if it was not yet, hands it to the thread and CONSUMES the handle
- *       (blocks while 8 frames are waiting);   mtr_device_exchange_drain: returns once every handed-over frame has been
+ *       (blocks while 8 frames are waiting; on an error return the handle is NOT consumed and stays the caller's);   mtr_device_exchange_drain: returns once every handed-over frame has been
  *       issued (not: finished on the GPU -- synchronise hip_stream for that) with the first error of the thread, if any;
  *   mtr_device_exchange_stop: drain + join (also done by mtr_device_destroy).
  * Frames of one device are still begun / drawn / submitted by ONE thread; only these calls cross threads. */
