@@ -110,6 +110,7 @@ def main():
     rc = None  # direct RCCL communicator (mt_renderer_amd/rccl.py), or None: torch.distributed's collective
     xthread = False  # the exchange runs on the library's exchange thread
     xstream = None
+    lane2 = None  # second exchange lane: (communicator, send, gathered, final, stream)
     if sharded:
         nbytes = int(api.lib.mtr_shard_bytes(W, H, world))
         shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
@@ -123,39 +124,42 @@ def main():
                 t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return bool(t.item())
-            try:
-                from mt_renderer_amd import rccl
-                rc = rccl.Rccl()
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] direct RCCL unavailable ({e}); using torch.distributed", file=sys.stderr)
-                rc = None
-            if all_ok(rc is not None):
+            import threading
+            from mt_renderer_amd import rccl
+
+            def make_comm(what):
+                """a communicator of this job's ranks, or None on EVERY rank if any step failed on any of them"""
+                try:
+                    c = rccl.Rccl()
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] direct RCCL unavailable ({e}); {what}", file=sys.stderr)
+                    c = None
+                if not all_ok(c is not None):
+                    return None
                 uid = None
                 if rank == 0:
                     try:
-                        uid = rc.unique_id()
+                        uid = c.unique_id()
                     except Exception as e:  # noqa: BLE001
-                        print(f"[rank 0] ncclGetUniqueId failed ({e}); using torch.distributed", file=sys.stderr)
+                        print(f"[rank 0] ncclGetUniqueId failed ({e}); {what}", file=sys.stderr)
                 box = [uid]
                 dist.broadcast_object_list(box, src=0)
                 ok = False
                 if box[0] is not None:
-                    import threading
                     # ncclCommInitRank is a blocking collective: if it cannot complete, end the run instead of hanging
                     guard = threading.Timer(180.0, lambda: (print(f"[rank {rank}] ncclCommInitRank did not return in 180 s",
                                                                   file=sys.stderr, flush=True), os._exit(5)))
                     guard.daemon = True
                     guard.start()
                     try:
-                        rc.init(box[0], world, rank)
+                        c.init(box[0], world, rank)
                         ok = True
                     except Exception as e:  # noqa: BLE001
-                        print(f"[rank {rank}] ncclCommInitRank failed ({e}); using torch.distributed", file=sys.stderr)
+                        print(f"[rank {rank}] ncclCommInitRank failed ({e}); {what}", file=sys.stderr)
                     guard.cancel()
-                if not all_ok(ok):
-                    rc = None
-            else:
-                rc = None
+                return c if all_ok(ok) else None
+
+            rc = make_comm("using torch.distributed")
             # With the direct communicator the whole exchange of a frame (pack -> ncclAllGather -> unpack -> destroy) moves
             # to the library's exchange thread (include/mtr.h: mtr_device_exchange_start): a rank's loop then costs the
             # host ~28-31 us per frame instead of ~43-51 (tools/probe/exchange_thread.py), which is what bounds N > 1 on this
@@ -173,6 +177,29 @@ def main():
                     xthread = True
                 elif started:
                     dev.exchange_stop()
+            # A lane is an in-order stream: it completes one (pack + all-gather + unpack) latency per frame.  A second lane
+            # with its own communicator takes every other frame, so two collectives are in flight -- but it is one more
+            # busy stream, and on the one GPU where it can be measured (world of one rank, the GPU rendering whole frames)
+            # the extra stream costs more than it hides: 0.091 ms per frame against 0.057 with one lane, for any
+            # GPU_MAX_HW_QUEUES from 8 to 24.  Off by default; MTR_BENCH_EXCHANGE_LANES=2 turns it on for an experiment on
+            # a real multi-GPU node, where the all-gather's latency may be what bounds the exchange stream.
+            want_lanes = int(os.environ.get("MTR_BENCH_EXCHANGE_LANES", "1"))
+            if xthread and want_lanes > 1:
+                rc2 = make_comm("one exchange lane")
+                if rc2 is not None:
+                    added = False
+                    try:
+                        lane2 = (rc2, torch.empty_like(shard), torch.empty_like(gathered), torch.empty_like(final), torch.cuda.Stream())
+                        dev.exchange_add_lane(rc2.comm_handle, lane2[1].data_ptr(), lane2[2].data_ptr(), lane2[3].data_ptr(),
+                                              lane2[4].cuda_stream)
+                        added = True
+                    except Exception as e:  # noqa: BLE001
+                        print(f"[rank {rank}] second exchange lane unavailable ({e})", file=sys.stderr)
+                    if not all_ok(added):
+                        # the lane count must be the same on every rank: without agreement, go back to the render thread
+                        dev.exchange_stop()
+                        xthread = False
+                        lane2 = None
 
     def one_frame(check=False):
         fr = api.Frame(dev, W, H)
@@ -244,6 +271,8 @@ def main():
         sync()
         got = final.cpu().numpy().reshape(H, W, 4)
         ok = bool((got == ref).all())
+        if lane2 is not None:  # odd frames went through the second lane into its own destination
+            ok = ok and bool((lane2[3].cpu().numpy().reshape(H, W, 4) == ref).all())
         print(f"[rank {rank}] verify gathered frame == unsharded frame: {ok}", file=sys.stderr, flush=True)
         if not ok:
             sys.exit(3)
@@ -336,7 +365,7 @@ def main():
             "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
                                    "64-bone palette, debug-id shader, %dx%d" % (W, H),
                        "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if sharded else "none",
-                       "collective": (("ncclAllGather (exchange thread)" if xthread else "ncclAllGather (ctypes)") if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
+                       "collective": ((("ncclAllGather (exchange thread, 2 lanes)" if lane2 is not None else "ncclAllGather (exchange thread)") if xthread else "ncclAllGather (ctypes)") if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
             "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))
@@ -346,6 +375,8 @@ def main():
         if rc is not None:
             torch.cuda.synchronize()
             rc.close()
+            if lane2 is not None:
+                lane2[0].close()
         dist.destroy_process_group()
 
 

@@ -186,10 +186,17 @@ int32_t mtr_device_unpack_color_shards_on_stream(mtr_device *dev, const void *ga
  *       (blocks while 8 frames are waiting; on an error return the handle is NOT consumed and stays the caller's);   mtr_device_exchange_drain: returns once every handed-over frame has been
  *       issued (not: finished on the GPU -- synchronise hip_stream for that) with the first error of the thread, if any;
  *   mtr_device_exchange_stop: drain + join (also done by mtr_device_destroy).
+ *   mtr_device_exchange_add_lane (optional, while the thread is idle, up to 4 lanes): one more (communicator, stream, send /
+ *       gathered / destination buffers) set; frames are dealt to the lanes in turn (the i-th frame handed over goes to
+ *       lane i % lanes, lane 0 being the one given to _start).  A lane is an in-order stream and completes one pack +
+ *       all-gather + unpack latency per frame; two lanes keep two collectives in flight.  Every rank must use the same
+ *       number of lanes, and each lane needs a communicator of its own.
  * Frames of one device are still begun / drawn / submitted by ONE thread; only these calls cross threads. */
 typedef int (*mtr_allgather_fn)(const void *send, void *recv, size_t count, int datatype, void *comm, void *stream);
 int32_t mtr_device_exchange_start(mtr_device *dev, mtr_allgather_fn fn, void *comm, int dtype_u8, void *send_dev,
                                   size_t send_bytes, void *gathered_dev, void *dst_dev, uint32_t world, void *hip_stream);
+int32_t mtr_device_exchange_add_lane(mtr_device *dev, void *comm, void *send_dev, void *gathered_dev, void *dst_dev,
+                                     void *hip_stream);
 int32_t mtr_frame_submit_exchange(mtr_frame *frame);
 int32_t mtr_device_exchange_drain(mtr_device *dev);
 int32_t mtr_device_exchange_stop(mtr_device *dev);

@@ -38,6 +38,9 @@ class Device {
                         void* dst_dev, uint32_t world, void* hip_stream) const {
         check(mtr_device_exchange_start(h_, fn, comm, dtype_u8, send_dev, send_bytes, gathered_dev, dst_dev, world, hip_stream));
     }
+    void exchange_add_lane(void* comm, void* send_dev, void* gathered_dev, void* dst_dev, void* hip_stream) const {
+        check(mtr_device_exchange_add_lane(h_, comm, send_dev, gathered_dev, dst_dev, hip_stream));
+    }
     void exchange_drain() const { check(mtr_device_exchange_drain(h_)); }
     void exchange_stop() const { check(mtr_device_exchange_stop(h_)); }
     void check(int32_t rc) const {

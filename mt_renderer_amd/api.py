@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_exchange_start", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
+    "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
 
@@ -122,6 +122,7 @@ def _load() -> C.CDLL:
         "mtr_frame_pack_color_shard_on_stream": (i32, [vp, vp, sz, vp]),
         "mtr_device_unpack_color_shards_on_stream": (i32, [vp, vp, u32, u32, u32, vp, vp]),
         "mtr_device_exchange_start": (i32, [vp, vp, vp, i32, vp, sz, vp, vp, u32, vp]),
+        "mtr_device_exchange_add_lane": (i32, [vp, vp, vp, vp, vp, vp]),
         "mtr_frame_submit_exchange": (i32, [vp]),
         "mtr_device_exchange_drain": (i32, [vp]),
         "mtr_device_exchange_stop": (i32, [vp]),
@@ -185,6 +186,11 @@ class Device:
         self.check(lib.mtr_device_exchange_start(self._h, C.c_void_p(allgather_fn_addr), C.c_void_p(comm), dtype_u8,
                                                  C.c_void_p(send_devptr), send_bytes, C.c_void_p(gathered_devptr),
                                                  C.c_void_p(dst_devptr), world, C.c_void_p(stream)))
+
+    def exchange_add_lane(self, comm: int, send_devptr: int, gathered_devptr: int, dst_devptr: int, stream: int):
+        """one more (communicator, buffers, stream) set for the exchange thread; frames go to the lanes in turn"""
+        self.check(lib.mtr_device_exchange_add_lane(self._h, C.c_void_p(comm), C.c_void_p(send_devptr), C.c_void_p(gathered_devptr),
+                                                    C.c_void_p(dst_devptr), C.c_void_p(stream)))
 
     def exchange_drain(self):
         """returns once every frame handed to the exchange thread has been issued; raises its first error"""

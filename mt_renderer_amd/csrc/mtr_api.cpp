@@ -114,6 +114,12 @@ struct Exchange {
     size_t send_bytes = 0;
     uint32_t world = 1;
     hipStream_t stream = nullptr;
+    // further lanes (mtr_device_exchange_add_lane): frames are dealt to the lanes in turn, lane 0 being the fields above.
+    // A lane is an in-order stream, so one lane completes one (pack + all-gather + unpack) latency per frame; two lanes
+    // with a communicator each keep two collectives in flight.
+    struct Lane { void* comm; uint8_t *send, *gathered, *dst; hipStream_t stream; };
+    std::vector<Lane> lanes;
+    uint64_t dealt = 0;  // frames taken by the thread so far
     std::thread th;
     std::mutex mu;
     std::condition_variable cv_items, cv_idle;
@@ -1327,15 +1333,16 @@ static void exchange_main(mtr_device* d, Exchange* x) {
         int32_t rc = x->err;
         std::string msg;
         if (rc == MTR_OK) {
-            rc = mtr_frame_pack_color_shard_on_stream(f, x->send, x->send_bytes, x->stream);
+            const Exchange::Lane ln = x->lanes[(size_t)(x->dealt++ % x->lanes.size())];
+            rc = mtr_frame_pack_color_shard_on_stream(f, ln.send, x->send_bytes, ln.stream);
             if (rc != MTR_OK) {
                 { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             } else {
-                const int nrc = x->fn(x->send, x->gathered, x->send_bytes, x->dtype_u8, x->comm, x->stream);
+                const int nrc = x->fn(ln.send, ln.gathered, x->send_bytes, x->dtype_u8, ln.comm, ln.stream);
                 if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
             }
             if (rc == MTR_OK) {
-                rc = mtr_device_unpack_color_shards_on_stream(d, x->gathered, x->world, f->w, f->h, x->dst, x->stream);
+                rc = mtr_device_unpack_color_shards_on_stream(d, ln.gathered, x->world, f->w, f->h, ln.dst, ln.stream);
                 if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             }
         }
@@ -1360,8 +1367,25 @@ int32_t mtr_device_exchange_start(mtr_device* d, mtr_allgather_fn fn, void* comm
     x->send = static_cast<uint8_t*>(send_dev); x->send_bytes = send_bytes;
     x->gathered = static_cast<uint8_t*>(gathered_dev); x->dst = static_cast<uint8_t*>(dst_dev);
     x->world = world; x->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    x->lanes.push_back({x->comm, x->send, x->gathered, x->dst, x->stream});
     d->xchg = x;
     x->th = std::thread(exchange_main, d, x);
+    return MTR_OK;
+}
+
+int32_t mtr_device_exchange_add_lane(mtr_device* d, void* comm, void* send_dev, void* gathered_dev, void* dst_dev, void* hip_stream) {
+    if (!d) return MTR_E_INVALID;
+    Exchange* x = d->xchg;
+    if (!x) return fail(d, MTR_E_INVALID, "no exchange thread (mtr_device_exchange_start)");
+    if (!send_dev || !gathered_dev || !dst_dev || !hip_stream) return fail(d, MTR_E_INVALID, "bad exchange lane arguments");
+    std::lock_guard<std::mutex> g(x->mu);
+    if (x->pending.load(std::memory_order_acquire) != 0) return fail(d, MTR_E_INVALID, "exchange lanes change only while the thread is idle");
+    if (x->lanes.size() >= 4) return fail(d, MTR_E_INVALID, "at most 4 exchange lanes");
+    for (const Exchange::Lane& ln : x->lanes)
+        if (ln.stream == hip_stream || ln.send == send_dev || ln.gathered == gathered_dev)
+            return fail(d, MTR_E_INVALID, "an exchange lane needs a stream and buffers of its own");
+    x->lanes.push_back({comm, static_cast<uint8_t*>(send_dev), static_cast<uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev),
+                        reinterpret_cast<hipStream_t>(hip_stream)});
     return MTR_OK;
 }
 
@@ -1414,7 +1438,7 @@ int32_t mtr_device_exchange_stop(mtr_device* d) {
     }
     x->cv_items.notify_all();
     x->th.join();
-    (void)hipStreamSynchronize(x->stream);
+    for (const Exchange::Lane& ln : x->lanes) (void)hipStreamSynchronize(ln.stream);
     d->xchg = nullptr;
     delete x;
     return rc;

@@ -107,6 +107,8 @@ extern "C" {
     pub fn mtr_device_exchange_start(dev: *mut mtr_device, fn_: mtr_allgather_fn, comm: *mut c_void, dtype_u8: i32,
                                      send_dev: *mut c_void, send_bytes: usize, gathered_dev: *mut c_void, dst_dev: *mut c_void,
                                      world: u32, hip_stream: *mut c_void) -> i32;
+    pub fn mtr_device_exchange_add_lane(dev: *mut mtr_device, comm: *mut c_void, send_dev: *mut c_void, gathered_dev: *mut c_void,
+                                        dst_dev: *mut c_void, hip_stream: *mut c_void) -> i32;
     pub fn mtr_frame_submit_exchange(frame: *mut mtr_frame) -> i32;
     pub fn mtr_device_exchange_drain(dev: *mut mtr_device) -> i32;
     pub fn mtr_device_exchange_stop(dev: *mut mtr_device) -> i32;

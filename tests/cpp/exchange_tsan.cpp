@@ -49,6 +49,10 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> send(nbytes), gathered(nbytes * world), final_((size_t)W * H * 4);
     int fake_stream = 0;
     REQ(mtr_device_exchange_start(dev, fake_allgather, nullptr, 1, send.data(), nbytes, gathered.data(), final_.data(), world, &fake_stream));
+    // a second lane: alternate frames use these buffers
+    std::vector<uint8_t> send2(nbytes), gathered2(nbytes * world), final2((size_t)W * H * 4);
+    int fake_stream2 = 0;
+    REQ(mtr_device_exchange_add_lane(dev, nullptr, send2.data(), gathered2.data(), final2.data(), &fake_stream2));
     const float clear[4] = {1, 1, 1, 1}, M[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     long handed = 0;
     for (long i = 0; i < frames; i++) {

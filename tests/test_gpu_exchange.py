@@ -31,18 +31,22 @@ def test_exchange_thread_rebuilds_the_unsharded_frame():
         shard = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
         gathered = torch.zeros(nbytes * world, dtype=torch.uint8, device="cuda")
         final = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda")
-        state = {"rank": 0, "calls": 0, "fail": False}
+        state = {"rank": 0, "calls": 0, "fail": False, "per_lane": {}}
 
         @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
         def fake_allgather(send, recv, count, dtype, comm, stream):
             state["calls"] += 1
             if state["fail"]:
                 return 7
-            assert send == shard.data_ptr() and recv == gathered.data_ptr() and count == nbytes and dtype == 1 and comm == 1234
-            with torch.cuda.stream(xs):
+            sh, ga, st, cm = lanes[send]
+            assert recv == ga.data_ptr() and count == nbytes and dtype == 1 and comm == cm and stream == st.cuda_stream
+            with torch.cuda.stream(st):
                 r = state["rank"]
-                gathered[r * nbytes:(r + 1) * nbytes].copy_(shard, non_blocking=True)
+                ga[r * nbytes:(r + 1) * nbytes].copy_(sh, non_blocking=True)
+            state["per_lane"][cm] = state["per_lane"].get(cm, 0) + 1
             return 0
+
+        lanes = {shard.data_ptr(): (shard, gathered, xs, 1234)}
 
         fr = api.Frame(dev, W, H); fr.set_shard(0, world); model.render(fr, M)
         with pytest.raises(api.MtrError):  # no exchange thread yet: the handle is not consumed
@@ -66,6 +70,25 @@ def test_exchange_thread_rebuilds_the_unsharded_frame():
         assert state["calls"] == world * nframes
         got = final.cpu().numpy().reshape(H, W, 4)
         assert (got == ref).all()
+        # a second lane (its own buffers, stream and "communicator"): frames alternate between the lanes
+        xs2 = torch.cuda.Stream()
+        shard2, gathered2, final2 = torch.zeros_like(shard), torch.zeros_like(gathered), torch.zeros_like(final)
+        lanes[shard2.data_ptr()] = (shard2, gathered2, xs2, 5678)
+        with pytest.raises(api.MtrError):  # a lane needs a stream and buffers of its own
+            dev.exchange_add_lane(5678, shard2.data_ptr(), gathered2.data_ptr(), final2.data_ptr(), xs.cuda_stream)
+        dev.exchange_add_lane(5678, shard2.data_ptr(), gathered2.data_ptr(), final2.data_ptr(), xs2.cuda_stream)
+        final.zero_()
+        state["per_lane"] = {}
+        for r in range(world):
+            state["rank"] = r
+            for _ in range(nframes):
+                fr = api.Frame(dev, W, H); fr.set_shard(r, world); model.render(fr, M)
+                fr.submit_exchange()
+            dev.exchange_drain()
+            torch.cuda.synchronize()
+        assert state["per_lane"] == {1234: nframes, 5678: nframes}
+        assert (final.cpu().numpy().reshape(H, W, 4) == ref).all()
+        assert (final2.cpu().numpy().reshape(H, W, 4) == ref).all()
         # a frame of another world size is refused before it reaches the thread
         fr = api.Frame(dev, W, H); fr.set_shard(0, 3); model.render(fr, M)
         with pytest.raises(api.MtrError):
