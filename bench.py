@@ -335,6 +335,8 @@ def main():
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                 "stage_ms_serial": {k: round(v, 5) for k, v in stage_ms_serial.items()},
                 "frame_gbps": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 3)}
+    if stats["binning"] == 1:  # single-pass binning: k_scan / k_fill are not launched at all
+        roofline["stage_note"] = "single-pass binning: no k_scan / k_fill launch; their entries are the gap between two timing events recorded back to back"
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
