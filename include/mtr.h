@@ -96,6 +96,10 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void *hip_stream, mtr_de
 void mtr_device_destroy(mtr_device *dev);
 const char *mtr_last_error(const mtr_device *dev); /* never NULL; dev may be NULL for create errors */
 int32_t mtr_device_set_profiling(mtr_device *dev, int32_t enable);
+/* wgpu::Device::poll(Maintain::Wait): returns once every frame submitted so far (and every exchange handed over) has
+ * left the GPU, with the error of any frame that was released without mtr_frame_wait and turned out to have overflowed
+ * its bin queues (MTR_E_OVERFLOW: that frame is missing triangles; later frames get larger queues). */
+int32_t mtr_device_synchronize(mtr_device *dev);
 /* tile-kernel choice.  AUTO: the visibility-key kernel when every material of the frame is opaque (debug-id /
  * overlay colours, textures whose alpha is 255 everywhere -- the blend is then a replace), else the ordered
  * kernel.  ORDERED forces the ordered kernel (tests compare both); VISIBILITY is honoured only when eligible. */
@@ -155,8 +159,13 @@ int32_t mtr_frame_draw_instances(mtr_frame *frame, mtr_model *model, const float
 /* DebugOverlay::render (src/debug_overlay.rs:202-221): n instanced cubes, no blend, constant colour */
 int32_t mtr_frame_draw_overlay_cubes(mtr_frame *frame, const float camera[16], const float *inst_mats,
                                      size_t n);
-int32_t mtr_frame_submit(mtr_frame *frame); /* enqueue all kernels; returns without waiting */
-int32_t mtr_frame_wait(mtr_frame *frame);   /* framebuffer complete in HBM; checks device flags */
+/* enqueue all kernels; returns without waiting.  A frame that is submitted and then destroyed (or consumed through its
+ * device pointers) without mtr_frame_wait cannot be re-run if a bounded bin queue overflows: its tile kernels then
+ * leave every bin at the clear colour instead of rendering from incomplete queues, and the NEXT mtr_frame_begin /
+ * mtr_frame_submit / mtr_device_synchronize returns MTR_E_OVERFLOW once (the bound has been raised by then). */
+int32_t mtr_frame_submit(mtr_frame *frame);
+/* framebuffer complete in HBM; a frame whose bin queues overflowed is transparently re-run first (exact two-pass queues) */
+int32_t mtr_frame_wait(mtr_frame *frame);
 int32_t mtr_frame_end(mtr_frame *frame);    /* submit + wait */
 int32_t mtr_frame_read_color(mtr_frame *frame, void *rgba8, size_t len);  /* width*height*4 */
 int32_t mtr_frame_read_depth(mtr_frame *frame, float *depth, size_t count); /* width*height */
@@ -182,6 +191,8 @@ int32_t mtr_device_unpack_color_shards_on_stream(mtr_device *dev, const void *ga
  * (send_dev, gathered_dev, send_bytes, dtype_u8, comm, hip_stream), so an RCCL host passes &ncclAllGather, its
  * communicator and ncclUint8; the library links no collective library itself.  Per frame the thread runs, on hip_stream:
  * pack (after the frame completes) -> fn -> unpack into dst_dev, then destroys the frame.
+ *   (a frame whose bin queues overflowed is re-run by the thread before it is packed: the gathered frame is never missing
+ *   triangles; the all-gather count is mtr_shard_bytes(frame width, height, world), which send_bytes must cover)
  *   mtr_frame_submit_exchange: submits the frame if it was not yet, hands it to the thread and CONSUMES the handle
  *       (blocks while 8 frames are waiting; on an error return the handle is NOT consumed and stays the caller's);   mtr_device_exchange_drain: returns once every handed-over frame has been
  *       issued (not: finished on the GPU -- synchronise hip_stream for that) with the first error of the thread, if any;

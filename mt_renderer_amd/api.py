@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
+    "mtr_device_synchronize", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
 
@@ -89,6 +89,7 @@ def _load() -> C.CDLL:
         "mtr_device_destroy": (None, [vp]),
         "mtr_last_error": (C.c_char_p, [vp]),
         "mtr_device_set_profiling": (i32, [vp, i32]),
+        "mtr_device_synchronize": (i32, [vp]),
         "mtr_texture_create": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(vp)]),
         "mtr_texture_destroy": (None, [vp]),
         "mtr_texture_read_rgba8": (i32, [vp, vp, sz]),
@@ -206,6 +207,10 @@ class Device:
     def set_binning(self, single_pass: bool, queue_capacity: int = 0):
         """single-pass bounded bin queues (default) or the exact two-pass queues; see include/mtr.h."""
         self.check(lib.mtr_device_set_binning(self._h, 1 if single_pass else 0, queue_capacity))
+
+    def synchronize(self):
+        """every submitted frame has left the GPU; raises if one that was never waited for dropped triangles"""
+        self.check(lib.mtr_device_synchronize(self._h))
 
     def set_profiling(self, on: bool):
         self.check(lib.mtr_device_set_profiling(self._h, 1 if on else 0))

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     __shared__ uint32_t s_pm[TRI_PASS];         // pair prefix | magic(bbox width) << 12
     __shared__ uint8_t s_tmap[TRI_PASS];        // compacted index -> triangle of the pass
 
-    zero_next_counters(P);
+    const uint32_t ovf = tile_prologue(P);
     const uint32_t lane = threadIdx.x;
     const uint32_t nbx = P.fb.nbx, nbins = nbx * P.fb.nby;
     const uint32_t world = P.fb.shard_world ? P.fb.shard_world : 1u;
@@ -148,6 +148,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
 
     uint32_t seg_lo, S, ent_lo, n_ent;
     bin_queue(P.fb, bin, ent_lo, n_ent, seg_lo, S);
+    if (ovf) { n_ent = 0; S = 0; }  // incomplete queues: read nothing, the bin stays cleared (tile_prologue)
     if (P.fb.direct && lane == 0 && n_ent) {  // queue statistics (direct mode has no scan to count them)
         atomicAdd(&P.fb.counters[MTR_CTR(CTR_ENT, bin)], n_ent);
         atomicAdd(&P.fb.counters[MTR_CTR(CTR_SEG, bin)], S);

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    zero_next_counters(P);
+    const uint32_t ovf = tile_prologue(P);
     uint32_t bin;
     if (!block_to_bin(P.fb, bin)) return;  // uniform over the workgroup, before any barrier
     const uint32_t nbx = P.fb.nbx;
@@ -174,6 +174,11 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     }
     uint32_t ent_lo, N, seg_lo_unused, n_seg;
     bin_queue(P.fb, bin, ent_lo, N, seg_lo_unused, n_seg);  // the same word for every thread of the workgroup
+    if (ovf) {  // incomplete queues: read nothing, leave the bin cleared and its fill word parked for the next frame
+        N = 0;
+        __syncthreads();  // every thread has read the fill word
+        if (threadIdx.x == 0) bin_queue_done(P.fb, bin);
+    }
     if (N == 0) {
         // an empty bin (a third of the headline frame): clear colour / depth and leave, no LDS, no barrier
         for (uint32_t pidx = threadIdx.x; pidx < MTR_BIN * MTR_BIN; pidx += 64 * VIS_WAVES) {

@@ -88,6 +88,23 @@ struct mtr_device {
     uint64_t frames_submitted = 0;  // index of the next frame; frame i records inflight[i % max_inflight]
     struct Garbage { void* p; uint64_t last_frame; };
     std::vector<Garbage> garbage;   // device buffers of destroyed batches whose last frame may still be in flight
+    // Everything a frame submission touches (slots, the in-flight ring, frames_submitted, garbage, the models' chunk
+    // tables and palette rings) is guarded by submit_mu: the render thread submits, but the exchange thread re-runs a
+    // frame whose bin queues overflowed and destroys frames (which may own batches).  Uncontended in steady state.
+    std::mutex submit_mu;
+    // Frame status words, pinned host memory, one per frame in flight (frame i uses word i % max_inflight): the tile
+    // kernel stores 0x80000000 | overflow flags there when it starts.  status_pending[i]: the frame that used word i
+    // was released (destroyed, or handed to a consumer) without anyone having looked at its flags; they are examined
+    // when the word is next polled / recycled, and a set flag is latched in sticky_err for the next API call to report.
+    uint32_t* status_host = nullptr;
+    uint32_t* status_dev = nullptr;
+    bool status_checked[kMaxInflight] = {};   // somebody (mtr_frame_wait, the exchange thread) has looked at the word
+    bool status_released[kMaxInflight] = {};  // its frame was destroyed without that: examine it at the next poll
+    uint64_t status_owner[kMaxInflight] = {}; // index of the frame the word belongs to
+    int status_slot_of[kMaxInflight] = {};    // which Slot that frame ran on
+    int32_t sticky_err = MTR_OK;
+    std::string sticky_msg;
+    uint32_t queue_scale = 1;  // two-pass queues: multiplier on the default sizes, doubled when an un-waited frame overflowed them
     hipStream_t s_copy = nullptr;  // small read-backs of finished frames (statistics), independent of frames in flight
     uint32_t frame_counter = 0;
     // single-pass binning (bounded per-bin queues); a frame that overflows them is re-run with the exact
@@ -151,7 +168,8 @@ struct mtr_model {
     // model is drawn and its stream waits on the event.  A ring buffer comes round again only after max_inflight + 1
     // palette changes; if the last frame that read it can still be in flight (many changes, few frames) the call waits
     // for exactly that frame first.
-    struct PalBuf { float* d = nullptr; uint32_t cap = 0; hipEvent_t ready = nullptr; uint64_t last_frame = 0; bool used = false; };
+    // pinned: frames that drew the model with this buffer and have not been submitted yet (their kernels will read it)
+    struct PalBuf { float* d = nullptr; uint32_t cap = 0; hipEvent_t ready = nullptr; uint64_t last_frame = 0; bool used = false; uint32_t pinned = 0; };
     std::vector<PalBuf> pal_ring;
     size_t pal_next = 0;
     hipEvent_t pal_ready = nullptr;  // of the current palette
@@ -199,6 +217,7 @@ struct Draw {
     int shader_override;                // -1 or MTR_SH_CONST (overlay)
     uint32_t const_rgba8;
     bool blend;
+    bool pal_pinned = false;  // holds a pin on the model's palette ring buffer pal_slot until the frame is submitted
     std::unique_ptr<mtr_batch, BatchDeleter> owned_batch;
 };
 
@@ -219,6 +238,10 @@ struct mtr_frame {
     int slot = 0;
     uint64_t min_entries = 0, min_segs = 0;  // queue sizes measured by a previous, overflowed attempt
     bool for_exchange = false;  // submitted through mtr_frame_submit_exchange: no public-stream consumer
+    int status_idx = -1;        // this frame's word of mtr_device::status_host (set by run_frame)
+    uint64_t frame_index = 0;   // its index in submission order (of the last run)
+    bool flags_checked = false; // somebody has examined this run's overflow flags
+    bool stats_valid = false;   // f->stats holds the device counters of the last run
 };
 
 namespace {
@@ -294,6 +317,60 @@ int32_t set_device(mtr_device* d) {
     return MTR_OK;
 }
 
+// Waits for everything the library has queued: the public stream and every slot stream (frames handed to the exchange
+// thread are not waited for by the public stream).  Used before freeing or overwriting what a frame in flight may read.
+int32_t drain_all(mtr_device* d) {
+    HIPCHK(d, hipStreamSynchronize(d->stream));
+    for (uint32_t i = 0; i < d->nslots; i++)
+        if (d->slots[i].stream) HIPCHK(d, hipStreamSynchronize(d->slots[i].stream));
+    return MTR_OK;
+}
+
+uint32_t status_load(const mtr_device* d, int i) { return __atomic_load_n(&d->status_host[i], __ATOMIC_ACQUIRE); }
+
+// bounded per-bin queues overflowed: later frames get twice the bound (up to 16384 entries per bin, then exact two-pass)
+void grow_direct_queues(mtr_device* d) {
+    if (d->qcap < 16384) { d->qcap *= 2; d->scap *= 2; }
+    else d->direct_enabled = false;
+}
+
+// A frame nobody waited for raised an overflow flag: its pixels are missing triangles and it is gone.  Latch an error
+// for the next API call that can report one, and raise the bounds so the frames that follow fit.  submit_mu held.
+void latch_overflow(mtr_device* d, uint32_t flags, uint64_t frame_index) {
+    if (flags & 4u) grow_direct_queues(d);
+    if (flags & 2u) d->queue_scale = std::min<uint32_t>(d->queue_scale * 2, 1024);
+    if (d->sticky_err == MTR_OK) {
+        d->sticky_err = MTR_E_OVERFLOW;
+        d->sticky_msg = "frame " + std::to_string(frame_index) + " overflowed its bin queues (flags " + std::to_string(flags) +
+                        ") and was never waited for: it is missing triangles; queue bounds raised for later frames";
+    }
+}
+
+// Looks at status word i if nobody has.  force: the word's frame is known to have left the GPU (a word that is still
+// invalid then belongs to a frame without a tile workgroup).  submit_mu held.
+void examine_status(mtr_device* d, int i, bool force) {
+    if (d->status_checked[i]) return;
+    const uint32_t v = status_load(d, i);
+    if (!(v & 0x80000000u) && !force) return;
+    d->status_checked[i] = true;
+    d->status_released[i] = false;
+    if (v & 0x7fffffffu) latch_overflow(d, v & 0x7fffffffu, d->status_owner[i]);
+}
+
+void poll_released(mtr_device* d) {
+    for (uint32_t i = 0; i < d->max_inflight; i++)
+        if (d->status_released[i]) examine_status(d, (int)i, false);
+}
+
+int32_t report_sticky(mtr_device* d) {
+    if (d->sticky_err == MTR_OK) return MTR_OK;
+    const int32_t rc = d->sticky_err;
+    const std::string msg = d->sticky_msg;
+    d->sticky_err = MTR_OK;
+    d->sticky_msg.clear();
+    return fail(d, rc, msg);
+}
+
 void rebuild_chunks(mtr_model* m) {
     m->chunks.clear();
     m->ntris_visible = 0;
@@ -355,6 +432,10 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
     }
     for (uint32_t i = 0; i < d->nslots; i++) HIPCHK(nullptr, hipStreamCreateWithFlags(&d->slots[i].stream, hipStreamNonBlocking));
     HIPCHK(nullptr, hipStreamCreateWithFlags(&d->s_copy, hipStreamNonBlocking));
+    HIPCHK(nullptr, hipHostMalloc(reinterpret_cast<void**>(&d->status_host), mtr_device::kMaxInflight * sizeof(uint32_t),
+                                  hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&d->status_dev), d->status_host, 0));
+    for (uint32_t i = 0; i < mtr_device::kMaxInflight; i++) { d->status_host[i] = 0x80000000u; d->status_checked[i] = true; }
     if (const char* e = getenv("MTR_MAX_INFLIGHT")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= (long)mtr_device::kMaxInflight) d->max_inflight = (uint32_t)v;
@@ -393,7 +474,19 @@ void mtr_device_destroy(mtr_device* d) {
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    if (d->status_host) (void)hipHostFree(d->status_host);
     delete d;
+}
+
+int32_t mtr_device_synchronize(mtr_device* d) {
+    if (!d) return MTR_E_INVALID;
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    if ((rc = mtr_device_exchange_drain(d))) return rc;
+    if ((rc = drain_all(d))) return rc;
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+    for (uint32_t i = 0; i < d->max_inflight; i++) examine_status(d, (int)i, true);  // every frame has left the GPU
+    return report_sticky(d);
 }
 
 int32_t mtr_device_set_tile_mode(mtr_device* d, int32_t mode) {
@@ -470,7 +563,7 @@ int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, 
 void mtr_texture_destroy(mtr_texture* t) {
     if (!t) return;
     (void)hipSetDevice(t->dev->hip_dev);
-    (void)hipStreamSynchronize(t->dev->stream);
+    (void)drain_all(t->dev);  // frames in flight (on any slot stream) may still sample it
     (void)hipFree(t->d_rgba);
     delete t;
 }
@@ -598,7 +691,7 @@ int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_le
 void mtr_model_destroy(mtr_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->dev->hip_dev);
-    (void)hipStreamSynchronize(m->dev->stream);
+    (void)drain_all(m->dev);  // frames in flight (on any slot stream) may still read its buffers
     for (auto& pb : m->pal_ring) {
         if (pb.d) (void)hipFree(pb.d);
         if (pb.ready) (void)hipEventDestroy(pb.ready);
@@ -622,22 +715,24 @@ int32_t mtr_model_set_palette(mtr_model* m, const float* mats, size_t n) {
     if (n > 256 || (!mats && n)) return fail(d, MTR_E_INVALID, "palette: at most 256 matrices (u8 joint indices)");
     int32_t rc = set_device(d);
     if (rc) return rc;
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
     m->npal = (uint32_t)n;
     m->d_palette = nullptr;
     m->pal_ready = nullptr;
     m->pal_slot = -1;
     if (n) {
-        if (m->pal_ring.size() != (size_t)d->max_inflight + 1) {  // first use (the bound is fixed at device creation)
-            HIPCHK(d, hipStreamSynchronize(d->stream));
+        if (m->pal_ring.size() != (size_t)d->max_inflight + 1)  // first use (the bound is fixed at device creation)
             m->pal_ring.resize((size_t)d->max_inflight + 1);
-        }
-        const size_t slot = m->pal_next++ % m->pal_ring.size();
+        size_t slot = m->pal_next++ % m->pal_ring.size();
+        for (size_t tries = 0; m->pal_ring[slot].pinned && tries < m->pal_ring.size(); tries++) slot = m->pal_next++ % m->pal_ring.size();
+        if (m->pal_ring[slot].pinned)
+            return fail(d, MTR_E_INVALID, "every palette buffer of the model is held by a frame that was drawn and not yet submitted");
         mtr_model::PalBuf& pb = m->pal_ring[slot];
         // the last frame that read this buffer: finished for sure once max_inflight later frames have been submitted
         if (pb.used && d->frames_submitted < pb.last_frame + 1 + d->max_inflight && d->inflight[pb.last_frame % d->max_inflight])
             HIPCHK(d, hipEventSynchronize(d->inflight[pb.last_frame % d->max_inflight]));
         if (pb.cap < n) {  // grow: nothing in flight may still read the old buffer
-            HIPCHK(d, hipStreamSynchronize(d->stream));
+            if ((rc = drain_all(d))) return rc;
             if (pb.d) (void)hipFree(pb.d);
             pb.d = nullptr; pb.cap = 0;
             if ((rc = dev_alloc(d, &pb.d, std::max<size_t>(n, 64) * 16))) return rc;
@@ -690,7 +785,9 @@ void mtr_batch_destroy(mtr_batch* b) {
     mtr_device* d = b->dev;
     (void)hipSetDevice(d->hip_dev);
     // a frame that drew the batch may still be in flight: park the buffers until that frame has left the GPU
-    // (collected at a later submit); otherwise free them now.  No stream is drained either way.
+    // (collected at a later submit); otherwise free them now.  No stream is drained either way.  The exchange thread
+    // destroys the batches its frames own while the render thread submits: submit_mu guards the list and the index.
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
     const bool busy = b->used && d->frames_submitted <= b->last_frame + d->max_inflight;
     for (void* p : {(void*)b->d_model_mats, (void*)b->d_palettes})
         if (p) {
@@ -711,6 +808,12 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
     if (w == 0 || h == 0 || w > 16384 || h > 16384 || !clear_rgba) return fail(d, MTR_E_INVALID, "bad frame size");
     int32_t rc = set_device(d);
     if (rc) return rc;
+    {
+        // an earlier frame that was released without a wait and turns out to have dropped triangles is reported here
+        std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+        poll_released(d);
+        if ((rc = report_sticky(d))) return rc;
+    }
     auto f = std::make_unique<mtr_frame>();
     f->dev = d; f->w = w; f->h = h;
     f->clear_rgba8 = pack_rgba8(clear_rgba);
@@ -771,6 +874,17 @@ void mtr_frame_destroy(mtr_frame* f) {
     if (f->have_events)
         for (auto& e : f->ev)
             if (e) (void)hipEventDestroy(e);
+    for (Draw& dr : f->draws)  // drawn, never submitted
+        if (dr.pal_pinned && dr.pal_slot >= 0 && (size_t)dr.pal_slot < dr.model->pal_ring.size()) {
+            std::lock_guard<std::mutex> g(d->submit_mu);
+            dr.model->pal_ring[(size_t)dr.pal_slot].pinned--;
+        }
+    if (f->submitted && !f->flags_checked && f->status_idx >= 0) {
+        // nobody looked at this frame's overflow flags: they are examined when its status word is polled or recycled,
+        // and a frame that dropped triangles is then reported by the next call that can return an error
+        std::lock_guard<std::mutex> g(d->submit_mu);
+        if (d->status_owner[f->status_idx] == f->frame_index && !d->status_checked[f->status_idx]) d->status_released[f->status_idx] = true;
+    }
     // the buffers may still be written by this frame's kernels: whoever recycles them waits on fb.done
     {
         std::lock_guard<std::mutex> g(d->pool_mu);
@@ -804,6 +918,11 @@ int32_t mtr_frame_draw_model(mtr_frame* f, mtr_model* m, const float view_proj[1
     dr.model = m; dr.d_model_mats = nullptr; dr.d_palettes = m->d_palette; dr.npal = m->npal; dr.pal_ready = m->pal_ready; dr.pal_slot = m->pal_slot;
     dr.pal_stride = 0; dr.ninst = 1; dr.shader_override = -1; dr.blend = true;
     memcpy(dr.vp, view_proj, sizeof dr.vp);
+    if (dr.pal_slot >= 0) {  // the ring buffer must not come round again before this frame has been submitted
+        std::lock_guard<std::mutex> submit_lock(f->dev->submit_mu);
+        m->pal_ring[(size_t)dr.pal_slot].pinned++;
+        dr.pal_pinned = true;
+    }
     f->draws.push_back(std::move(dr));
     return MTR_OK;
 }
@@ -870,6 +989,7 @@ int32_t mtr_frame_draw_overlay_cubes(mtr_frame* f, const float camera[16], const
     return MTR_OK;
 }
 
+// Enqueues every kernel of the frame.  The caller holds d->submit_mu.
 static int32_t run_frame(mtr_frame* f) {
     mtr_device* d = f->dev;
     int32_t rc = set_device(d);
@@ -881,7 +1001,7 @@ static int32_t run_frame(mtr_frame* f) {
         mtr_model* m = dr.model;
         if (m->chunks_dirty) {
             rebuild_chunks(m);
-            if (m->d_chunks) { HIPCHK(d, hipStreamSynchronize(d->stream)); (void)hipFree(m->d_chunks); m->d_chunks = nullptr; }
+            if (m->d_chunks) { if ((rc = drain_all(d))) return rc; (void)hipFree(m->d_chunks); m->d_chunks = nullptr; }
             if ((rc = dev_alloc(d, &m->d_chunks, m->chunks.size()))) return rc;
             HIPCHK(d, hipMemcpyAsync(m->d_chunks, m->chunks.data(), m->chunks.size() * sizeof(DChunk), hipMemcpyHostToDevice, d->stream));
             HIPCHK(d, hipStreamSynchronize(d->stream));
@@ -898,6 +1018,12 @@ static int32_t run_frame(mtr_frame* f) {
     hipEvent_t& ring = d->inflight[this_frame % d->max_inflight];
     if (ring) HIPCHK(d, hipEventSynchronize(ring));  // frame (i - max_inflight) has left the GPU
     else HIPCHK(d, hipEventCreateWithFlags(&ring, hipEventDisableTiming));
+    // its status word is recycled for this frame: if nobody looked at that frame's overflow flags, do it now
+    const int sidx = (int)(this_frame % d->max_inflight);
+    examine_status(d, sidx, true);
+    __atomic_store_n(&d->status_host[sidx], 0u, __ATOMIC_RELEASE);
+    d->status_checked[sidx] = false; d->status_released[sidx] = false; d->status_owner[sidx] = this_frame;
+    f->status_idx = sidx; f->frame_index = this_frame; f->flags_checked = false; f->stats_valid = false;
     // every frame up to this_frame - max_inflight has been waited for: collect what only they could still read
     if (!d->garbage.empty()) {
         size_t keep = 0;
@@ -908,11 +1034,12 @@ static int32_t run_frame(mtr_frame* f) {
         d->garbage.resize(keep);
     }
     f->slot = (int)(d->frame_counter++ % d->nslots);
+    d->status_slot_of[sidx] = f->slot;
     Slot& sl = d->slots[f->slot];
     const uint64_t rec_need = total_chunks * MTR_CHUNK_SLOTS;
     if (rec_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many triangles in one frame");
     if (rec_need > sl.rec_cap || !sl.rec_a) {
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        HIPCHK(d, hipStreamSynchronize(sl.stream));
         uint32_t c0 = sl.rec_cap, c1 = sl.rec_cap, c2 = sl.rec_cap;
         if ((rc = dev_grow(d, &sl.rec_hdr, &c0, rec_need))) return rc;
         if ((rc = dev_grow(d, &sl.rec_a, &c1, rec_need))) return rc;
@@ -920,11 +1047,12 @@ static int32_t run_frame(mtr_frame* f) {
         sl.rec_cap = c0;
     }
     if (total_chunks > sl.chunk_cap || !sl.chunk_info) {
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        HIPCHK(d, hipStreamSynchronize(sl.stream));
         if ((rc = dev_grow(d, &sl.chunk_info, &sl.chunk_cap, total_chunks))) return rc;
     }
     if (nbins + 1 > sl.bin_cap || !sl.bin_count) {
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        HIPCHK(d, hipStreamSynchronize(sl.stream));
+        HIPCHK(d, hipStreamSynchronize(d->stream));  // mtr_frame_read_bin_counts copies from them on the public stream
         uint32_t c0 = sl.bin_cap, c1 = sl.bin_cap, c2 = sl.bin_cap, c3 = sl.bin_cap;
         if ((rc = dev_grow(d, &sl.bin_count, &c0, nbins + 1))) return rc;
         if ((rc = dev_grow(d, &sl.bin_fill, &c1, nbins + 1))) return rc;
@@ -940,7 +1068,7 @@ static int32_t run_frame(mtr_frame* f) {
         // be addressable with 32 bits
         while ((uint64_t)nbins * d->qcap > 0xF0000000ull && d->qcap > 64) d->qcap /= 2;
         f->ran_direct = d->direct_enabled && !f->force_two_pass;
-        uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2), s_need = std::max<uint64_t>(1u << 18, total_chunks * 8);
+        uint64_t e_need = std::max<uint64_t>(1u << 20, rec_need / 2) * d->queue_scale, s_need = std::max<uint64_t>(1u << 18, total_chunks * 8) * d->queue_scale;
         e_need = std::max<uint64_t>(e_need, f->min_entries);
         s_need = std::max<uint64_t>(s_need, f->min_segs);
         if (f->ran_direct) {
@@ -948,11 +1076,11 @@ static int32_t run_frame(mtr_frame* f) {
             s_need = std::max<uint64_t>(s_need, (uint64_t)nbins * d->scap);
         }
         if (e_need > sl.entry_cap || !sl.entries) {
-            HIPCHK(d, hipStreamSynchronize(d->stream));
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
             if ((rc = dev_grow(d, &sl.entries, &sl.entry_cap, std::min<uint64_t>(e_need, 0xFFFFFFF0ull)))) return rc;
         }
         if (s_need > sl.seg_cap || !sl.segs) {
-            HIPCHK(d, hipStreamSynchronize(d->stream));
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
             if ((rc = dev_grow(d, &sl.segs, &sl.seg_cap, std::min<uint64_t>(s_need, 0xFFFFFFF0ull)))) return rc;
         }
     }
@@ -990,7 +1118,7 @@ static int32_t run_frame(mtr_frame* f) {
             }
     }
     if (mats.size() > sl.mat_cap || !sl.mats) {
-        HIPCHK(d, hipStreamSynchronize(d->stream));
+        HIPCHK(d, hipStreamSynchronize(sl.stream));
         if ((rc = dev_grow(d, &sl.mats, &sl.mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
         sl.mats_uploaded.clear();
     }
@@ -1044,8 +1172,10 @@ static int32_t run_frame(mtr_frame* f) {
         if (dr.pal_ready) {  // uploads of a model palette (ring) or of a batch, made on the copy stream
             HIPCHK(d, hipStreamWaitEvent(sg, dr.pal_ready, 0));
             if (dr.pal_slot >= 0 && (size_t)dr.pal_slot < m->pal_ring.size()) {
-                m->pal_ring[(size_t)dr.pal_slot].last_frame = this_frame;
-                m->pal_ring[(size_t)dr.pal_slot].used = true;
+                mtr_model::PalBuf& pb = m->pal_ring[(size_t)dr.pal_slot];
+                pb.last_frame = this_frame;
+                pb.used = true;
+                if (dr.pal_pinned) { pb.pinned--; dr.pal_pinned = false; }  // from here on last_frame protects it
             }
         }
         gp.model_mats = dr.d_model_mats; gp.palettes = dr.d_palettes; gp.npal = dr.d_palettes ? dr.npal : 0;
@@ -1075,6 +1205,7 @@ static int32_t run_frame(mtr_frame* f) {
     tp.bin_flag = sl.bin_flag; tp.mixed = mixed ? 1u : 0u;
     tp.zero_next = f->fb.other();
     f->fb.next_zeroed = true;
+    tp.host_status = d->status_dev + sidx;
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
     if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
     if (!use_vis) mtr_launch_tile(tp, any_textured, st);
@@ -1098,11 +1229,63 @@ static int32_t run_frame(mtr_frame* f) {
 
 int32_t mtr_frame_submit(mtr_frame* f) {
     if (!f) return MTR_E_INVALID;
-    if (f->submitted) return fail(f->dev, MTR_E_INVALID, "frame already submitted");
-    int32_t rc = run_frame(f);
+    mtr_device* d = f->dev;
+    if (f->submitted) return fail(d, MTR_E_INVALID, "frame already submitted");
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+    poll_released(d);
+    int32_t rc = report_sticky(d);  // an earlier frame that nobody waited for dropped triangles
+    if (rc) return rc;
+    rc = run_frame(f);
     if (rc) return rc;
     f->submitted = true;
     return MTR_OK;
+}
+
+// Makes sure the frame's kernels ran with complete bin queues: reads the overflow flags its tile kernel published and,
+// when one is set, re-runs the frame (bounded per-bin queue full: through the exact two-pass queues, and later frames get
+// twice the bound; two-pass queues too small: grown to what the scan measured).  wait_done: block until the frame has
+// left the GPU first (mtr_frame_wait); otherwise return as soon as the flags are known to be clean, which the tile
+// kernel announces when it STARTS -- the exchange thread can then queue the pack behind the frame without a host-side
+// wait for its completion.  Called by the render thread and by the exchange thread (run_frame under submit_mu).
+static int32_t settle_frame(mtr_frame* f, bool wait_done) {
+    mtr_device* d = f->dev;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        uint32_t v = 0;
+        if (!wait_done)
+            for (int spin = 0; spin < 100000 && !((v = status_load(d, f->status_idx)) & 0x80000000u); spin++) __builtin_ia32_pause();
+        if (!(v & 0x80000000u)) {
+            HIPCHK(d, hipEventSynchronize(f->fb.done));
+            v = status_load(d, f->status_idx);  // still 0: no tile workgroup ran (a rank that owns no bin), nothing to check
+        }
+        const uint32_t flags = v & 0x7fffffffu;
+        {
+            std::lock_guard<std::mutex> g(d->submit_mu);
+            if (d->status_owner[f->status_idx] == f->frame_index) d->status_checked[f->status_idx] = true;
+        }
+        f->flags_checked = true;
+        if (!flags) return MTR_OK;
+        if (flags & 1u) return fail(d, MTR_E_OVERFLOW, "record capacity exceeded (internal bound violated)");
+        if (!(flags & 4u)) {
+            // exact queues too small: grow to what the scan measured
+            uint32_t two[2] = {0, 0};
+            HIPCHK(d, hipEventSynchronize(f->fb.done));
+            HIPCHK(d, hipMemcpyAsync(two, f->fb.live() + CTR_ENTRIES, sizeof two, hipMemcpyDeviceToHost, d->s_copy));
+            HIPCHK(d, hipStreamSynchronize(d->s_copy));
+            const uint64_t e_need = (uint64_t)two[0] + two[0] / 4 + 1024, s_need = (uint64_t)two[1] + two[1] / 4 + 1024;
+            if (e_need > 0xFFFFFFF0ull || s_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "bin queues exceed 2^32 entries");
+            f->min_entries = e_need;  // run_frame grows the queues of the slot it picks
+            f->min_segs = s_need;
+        }
+        std::lock_guard<std::mutex> g(d->submit_mu);
+        if (flags & 4u) {
+            // a bounded per-bin queue filled up: this frame takes the exact two-pass path, later frames get twice the bound
+            f->force_two_pass = true;
+            grow_direct_queues(d);
+        }
+        const int32_t rc = run_frame(f);
+        if (rc) return rc;
+    }
+    return fail(d, MTR_E_OVERFLOW, "bin queues still overflow after growing");
 }
 
 int32_t mtr_frame_wait(mtr_frame* f) {
@@ -1112,49 +1295,38 @@ int32_t mtr_frame_wait(mtr_frame* f) {
     if (f->waited) return MTR_OK;
     int32_t rc = set_device(d);
     if (rc) return rc;
-    for (int attempt = 0; attempt < 5; attempt++) {
-        uint32_t ctr[CTR_NUM];
-        // wait for THIS frame only (the public stream also carries the completion of every later frame)
-        HIPCHK(d, hipEventSynchronize(f->fb.done));
-        HIPCHK(d, hipMemcpyAsync(ctr, f->fb.live(), sizeof ctr, hipMemcpyDeviceToHost, d->s_copy));
-        HIPCHK(d, hipStreamSynchronize(d->s_copy));
-        f->stats.tris_setup = 0;
-        for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[MTR_CTR(CTR_REC, k)];
-        f->stats.bin_entries = ctr[CTR_ENTRIES];
-        f->stats.segments = ctr[CTR_SEGS];
-        if (f->ran_direct) {  // no scan in direct mode: the tile kernels counted the queues
-            f->stats.bin_entries = f->stats.segments = 0;
-            for (int k = 0; k < CTR_NSHARDS; k++) {
-                f->stats.bin_entries += ctr[MTR_CTR(CTR_ENT, k)];
-                f->stats.segments += ctr[MTR_CTR(CTR_SEG, k)];
-            }
+    // wait for THIS frame only (the public stream also carries the completion of every later frame)
+    if ((rc = settle_frame(f, true))) return rc;
+    HIPCHK(d, hipEventSynchronize(f->fb.done));  // of the last run
+    if (d->profiling && f->have_events)
+        for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
+    f->waited = true;
+    return MTR_OK;
+}
+
+// device counters of the finished frame -> f->stats (read back on demand: mtr_frame_wait itself copies nothing)
+static int32_t fetch_stats(mtr_frame* f) {
+    mtr_device* d = f->dev;
+    int32_t rc = mtr_frame_wait(f);
+    if (rc) return rc;
+    if (f->stats_valid) return MTR_OK;
+    uint32_t ctr[CTR_NUM];
+    HIPCHK(d, hipMemcpyAsync(ctr, f->fb.live(), sizeof ctr, hipMemcpyDeviceToHost, d->s_copy));
+    HIPCHK(d, hipStreamSynchronize(d->s_copy));
+    f->stats.tris_setup = 0;
+    for (int k = 0; k < CTR_NSHARDS; k++) f->stats.tris_setup += ctr[MTR_CTR(CTR_REC, k)];
+    f->stats.bin_entries = ctr[CTR_ENTRIES];
+    f->stats.segments = ctr[CTR_SEGS];
+    if (f->ran_direct) {  // no scan in direct mode: the tile kernels counted the queues
+        f->stats.bin_entries = f->stats.segments = 0;
+        for (int k = 0; k < CTR_NSHARDS; k++) {
+            f->stats.bin_entries += ctr[MTR_CTR(CTR_ENT, k)];
+            f->stats.segments += ctr[MTR_CTR(CTR_SEG, k)];
         }
-        f->stats.binning = f->ran_direct ? 1u : 2u;
-        if (!ctr[CTR_OVERFLOW]) {
-            if (d->profiling && f->have_events)
-                for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
-            f->waited = true;
-            return MTR_OK;
-        }
-        if (ctr[CTR_OVERFLOW] & 1u) return fail(d, MTR_E_OVERFLOW, "record capacity exceeded (internal bound violated)");
-        if (ctr[CTR_OVERFLOW] & 4u) {
-            // a bounded per-bin queue filled up: this frame takes the exact two-pass path, later frames get twice the bound
-            f->force_two_pass = true;
-            HIPCHK(d, hipStreamSynchronize(d->stream));
-            if (d->qcap < 16384) { d->qcap *= 2; d->scap *= 2; }
-            else d->direct_enabled = false;
-            if ((rc = run_frame(f))) return rc;
-            continue;
-        }
-        // bin queues too small: grow to what the scan measured and run the frame again
-        const uint64_t e_need = (uint64_t)ctr[CTR_ENTRIES] + ctr[CTR_ENTRIES] / 4 + 1024;
-        const uint64_t s_need = (uint64_t)ctr[CTR_SEGS] + ctr[CTR_SEGS] / 4 + 1024;
-        if (e_need > 0xFFFFFFF0ull || s_need > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "bin queues exceed 2^32 entries");
-        f->min_entries = e_need;  // run_frame grows the queues of the slot it picks
-        f->min_segs = s_need;
-        if ((rc = run_frame(f))) return rc;
     }
-    return fail(d, MTR_E_OVERFLOW, "bin queues still overflow after growing");
+    f->stats.binning = f->ran_direct ? 1u : 2u;
+    f->stats_valid = true;
+    return MTR_OK;
 }
 
 int32_t mtr_frame_end(mtr_frame* f) {
@@ -1241,7 +1413,7 @@ int32_t mtr_device_unpack_color_shards_on_stream(mtr_device* d, const void* gath
 
 int32_t mtr_frame_get_stats(mtr_frame* f, mtr_frame_stats* out) {
     if (!f || !out) return MTR_E_INVALID;
-    int32_t rc = mtr_frame_wait(f);
+    int32_t rc = fetch_stats(f);
     if (rc) return rc;
     *out = f->stats;
     return MTR_OK;
@@ -1330,15 +1502,22 @@ static void exchange_main(mtr_device* d, Exchange* x) {
             f = x->q.front(); x->q.pop_front();
         }
         x->cv_items.notify_all();  // room in the queue
-        int32_t rc = x->err;
+        int32_t rc;
+        { std::lock_guard<std::mutex> g(x->mu); rc = x->err; }
         std::string msg;
         if (rc == MTR_OK) {
             const Exchange::Lane ln = x->lanes[(size_t)(x->dealt++ % x->lanes.size())];
-            rc = mtr_frame_pack_color_shard_on_stream(f, ln.send, x->send_bytes, ln.stream);
+            // a frame whose bin queues overflowed is re-run (exact two-pass queues) BEFORE its colour is packed: the
+            // gathered frame is never missing triangles.  The flags are known when the frame's tile kernel starts, so
+            // in the normal case this does not wait for the frame to finish.
+            rc = settle_frame(f, false);
+            // every rank sends exactly its shard of THIS frame: the unpack derives the per-rank stride from the frame size
+            const size_t count = mtr_shard_bytes(f->w, f->h, x->world);
+            if (rc == MTR_OK) rc = mtr_frame_pack_color_shard_on_stream(f, ln.send, count, ln.stream);
             if (rc != MTR_OK) {
                 { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             } else {
-                const int nrc = x->fn(ln.send, ln.gathered, x->send_bytes, x->dtype_u8, ln.comm, ln.stream);
+                const int nrc = x->fn(ln.send, ln.gathered, count, x->dtype_u8, ln.comm, ln.stream);
                 if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
             }
             if (rc == MTR_OK) {
@@ -1396,6 +1575,7 @@ int32_t mtr_frame_submit_exchange(mtr_frame* f) {
     if (!x) return fail(d, MTR_E_INVALID, "no exchange thread (mtr_device_exchange_start)");
     if (f->shard_world != x->world) return fail(d, MTR_E_INVALID, "frame shard world differs from the exchange's");
     if (x->send_bytes < mtr_shard_bytes(f->w, f->h, x->world)) return fail(d, MTR_E_INVALID, "exchange send buffer too small");
+    if (f->waited) f->flags_checked = true;
     if (!f->submitted) {
         f->for_exchange = true;  // its only consumer is the exchange thread, which waits for the frame on its own stream
         int32_t rc = mtr_frame_submit(f);
@@ -1446,16 +1626,18 @@ int32_t mtr_device_exchange_stop(mtr_device* d) {
 
 uint32_t mtr_crc32(const uint8_t* bytes, size_t len, uint32_t init) {
     // src/util/crc.rs:36-50: reflected 0xEDB88320 table, no final xor, stops at the first NUL
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
-        for (uint32_t i = 0; i < 256; i++) {
-            uint32_t c = i;
-            for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
-            table[i] = c;
+    struct Table {
+        uint32_t t[256];
+        constexpr Table() : t() {
+            for (uint32_t i = 0; i < 256; i++) {
+                uint32_t c = i;
+                for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+                t[i] = c;
+            }
         }
-        ready = true;
-    }
+    };
+    static constexpr Table kTable{};  // constant-initialised: no lazy set-up for two threads to race on
+    const uint32_t* table = kTable.t;
     uint32_t v = init;
     for (size_t i = 0; i < len && bytes[i] != 0; i++) v = table[(bytes[i] ^ v) & 0xff] ^ (v >> 8);
     return v;

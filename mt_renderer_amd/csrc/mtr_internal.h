@@ -162,6 +162,10 @@ struct TileParams {
     // the counter block the NEXT frame on these framebuffers will use (CTR_NUM words), zeroed by this frame's tile
     // kernel so that no fill has to be launched per frame; nullptr: nothing to zero
     uint32_t* zero_next;
+    // one word of pinned host memory per frame in flight: the tile kernel publishes 0x80000000 | CTR_OVERFLOW there as
+    // soon as it starts (the geometry / scan kernels that raise the flags have completed by then), so the host -- the
+    // render thread, or the exchange thread before it packs -- learns about a dropped triangle without a read-back
+    uint32_t* host_status;
 };
 
 // launchers (defined in the .hip files, called from mtr_api.cpp)

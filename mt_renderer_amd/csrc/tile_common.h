@@ -11,6 +11,18 @@ __device__ __forceinline__ void zero_next_counters(const TileParams& P) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)CTR_NUM; i += gridDim.x * blockDim.x) P.zero_next[i] = 0u;
 }
 
+// Start of every tile workgroup.  Returns the frame's overflow flags (final: the kernels that raise them precede this
+// one on the stream) and publishes them to the host's status word.  A frame with a flag set has incomplete queues --
+// slots that were reserved and never written -- so the tile kernels must not read them: they clear their bin, park the
+// fill word and leave; the host re-runs the frame (mtr_frame_wait, the exchange thread) or latches an error.
+__device__ __forceinline__ uint32_t tile_prologue(const TileParams& P) {
+    zero_next_counters(P);
+    const uint32_t ovf = P.fb.counters[CTR_OVERFLOW];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.host_status)
+        __hip_atomic_store(P.host_status, 0x80000000u | ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return ovf;
+}
+
 // byte / 255, bit-identical to the IEEE division SPEC.md spells, in three instructions instead of the ten of the
 // correctly rounded divide expansion: q0 = x * r, e = fma(-q0, 255, x), q = fma(e, r, q0), r = RN(1 / 255).  Verified
 // for all 256 bytes with exact rational arithmetic (tests/test_div_exact.py; the bare product x * r is wrong for 126

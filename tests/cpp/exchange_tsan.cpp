@@ -10,8 +10,10 @@
 void mtr_launch_geom(const GeomParams&, hipStream_t) {}
 void mtr_launch_scan(const FrameBuffers&, hipStream_t) {}
 void mtr_launch_fill(const FrameBuffers&, uint32_t, hipStream_t) {}
-void mtr_launch_tile(const TileParams&, bool, hipStream_t) {}
-void mtr_launch_tile_vis(const TileParams&, bool, hipStream_t) {}
+// what tile_prologue does on the device: publish the (clean) overflow flags of the frame
+static void stub_status(const TileParams& p) { if (p.host_status) __atomic_store_n(p.host_status, 0x80000000u, __ATOMIC_RELEASE); }
+void mtr_launch_tile(const TileParams& p, bool, hipStream_t) { stub_status(p); }
+void mtr_launch_tile_vis(const TileParams& p, bool, hipStream_t) { stub_status(p); }
 void mtr_launch_alpha_min(const uint8_t*, size_t, uint32_t* out_min, hipStream_t) { *out_min = 255; }
 void mtr_launch_vertex_stage(const GeomParams&, uint32_t, float*, float*, hipStream_t) {}
 void mtr_launch_bc1_decode(const uint8_t*, uint8_t*, uint32_t, uint32_t, hipStream_t) {}

@@ -9,8 +9,10 @@
 void mtr_launch_geom(const GeomParams&, hipStream_t) {}
 void mtr_launch_scan(const FrameBuffers&, hipStream_t) {}
 void mtr_launch_fill(const FrameBuffers&, uint32_t, hipStream_t) {}
-void mtr_launch_tile(const TileParams&, bool, hipStream_t) {}
-void mtr_launch_tile_vis(const TileParams&, bool, hipStream_t) {}
+// what tile_prologue does on the device: publish the (clean) overflow flags of the frame
+static void stub_status(const TileParams& p) { if (p.host_status) __atomic_store_n(p.host_status, 0x80000000u, __ATOMIC_RELEASE); }
+void mtr_launch_tile(const TileParams& p, bool, hipStream_t) { stub_status(p); }
+void mtr_launch_tile_vis(const TileParams& p, bool, hipStream_t) { stub_status(p); }
 void mtr_launch_alpha_min(const uint8_t* rgba, size_t npixels, uint32_t* out_min, hipStream_t) {
     uint32_t m = 255;
     for (size_t i = 0; i < npixels; i++) m = std::min<uint32_t>(m, rgba[4 * i + 3]);  // reads every texel: ASan checks the size
