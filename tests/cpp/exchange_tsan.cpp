@@ -61,7 +61,16 @@ int main(int argc, char** argv) {
         mtr_frame* f = nullptr;
         REQ(mtr_frame_begin(dev, W, H, clear, 1.0f, &f));
         REQ(mtr_frame_set_shard(f, (uint32_t)(i & 1), world));
-        REQ(mtr_frame_draw_model(f, model, M));
+        if (i % 5 == 2) {
+            // a frame that OWNS a temporary batch: the exchange thread destroys it (mtr_batch_destroy: garbage list,
+            // frame index) while this thread keeps submitting
+            const float inst[32] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0.1f, 0, 0, 1};
+            REQ(mtr_frame_draw_instances(f, model, inst, nullptr, 0, 2, M));
+        } else if (i % 5 == 4) {
+            REQ(mtr_frame_draw_overlay_cubes(f, M, M, 1));
+        } else {
+            REQ(mtr_frame_draw_model(f, model, M));
+        }
         if (i % 7 == 3) {  // a frame that is submitted, waited and destroyed here: the pool is used from this thread too
             REQ(mtr_frame_submit(f));
             REQ(mtr_frame_wait(f));
