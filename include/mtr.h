@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MTR_ABI_VERSION 1
+#define MTR_ABI_VERSION 2
 
 enum {
     MTR_OK = 0,
@@ -83,6 +83,11 @@ typedef struct mtr_frame_stats {
     uint32_t width, height, nbins, ndraws;
     uint32_t tile_kernel; /* MTR_TILE_ORDERED, MTR_TILE_VISIBILITY or MTR_TILE_MIXED: which tile kernel(s) rendered the frame */
     uint32_t binning;     /* 1 = single-pass bounded queues, 2 = exact two-pass (count, scan, fill) queues */
+    uint64_t chunks;        /* geometry waves of the frame (62 strip positions each, per instance) */
+    uint64_t chunks_culled; /* of those, skipped by this rank before any vertex work: bounds outside its bins (sharded frames;
+                             * the chunks of instances culled as a whole are not counted) */
+    uint32_t shard_map;     /* MTR_OWN_* */
+    uint32_t shard_bins;    /* bins this rank rendered */
 } mtr_frame_stats;
 
 /* stage timings of the last submitted frame, milliseconds, from hipEvents recorded on the
@@ -146,9 +151,24 @@ void mtr_batch_destroy(mtr_batch *batch);
 /* ---- frame = one render pass (src/bin/modelviewer.rs:190-210: clear colour / clear depth) ---- */
 int32_t mtr_frame_begin(mtr_device *dev, uint32_t width, uint32_t height, const float clear_rgba[4],
                         float clear_depth, mtr_frame **out);
-/* renders only bins with (bin_index % world) == rank; colour/depth of other bins are untouched.
- * The sharded colour is exchanged by the caller (RCCL all-gather, see bench.py). */
+/* Multi-GPU, one process per GPU: the frame renders only the 16x16-pixel bins that `rank` of `world` owns; colour / depth
+ * of the other bins are untouched.  The sharded colour is exchanged by the caller (RCCL all-gather, see bench.py).
+ * Which bins a rank owns is the host's choice, per frame (every rank of a frame must make the same choice):
+ *   MTR_OWN_INTERLEAVED  bin b (row-major) -> rank b % world.  Finest balance; every object touches every rank.
+ *   MTR_OWN_BANDS        rank r owns the bin rows [band_rows[r], band_rows[r+1]) (band_rows[0] = 0, band_rows[world] =
+ *                        ceil(height / 16), non-decreasing; NULL = equal bands).  An object touches the few ranks
+ *                        whose bands it crosses, so the geometry a rank must process shrinks with the world.
+ *   MTR_OWN_SUPERTILES   squares of (1 << param) x (1 << param) bins (param <= 6) dealt round-robin, row-major.
+ * A sharded rank does not process geometry that cannot reach its bins: every geometry wave first tests the object-space
+ * bounds of its 62 strip positions (one box per joint that carries weight, transformed by that joint's palette matrix
+ * and the view-projection; computed at mtr_model_create) against the rank's bins, and a batch draw first compacts its
+ * instance list the same way.  The test is conservative: the pixels of a rank's bins are exactly those of the unsharded
+ * frame.  mtr_device_set_culling(dev, 0) turns it off (tests compare both).  mtr_frame_set_shard = INTERLEAVED. */
+enum { MTR_OWN_INTERLEAVED = 0, MTR_OWN_BANDS = 1, MTR_OWN_SUPERTILES = 2 };
 int32_t mtr_frame_set_shard(mtr_frame *frame, uint32_t rank, uint32_t world);
+int32_t mtr_frame_set_shard_map(mtr_frame *frame, uint32_t rank, uint32_t world, uint32_t map, uint32_t param,
+                                const uint32_t *band_rows /* world + 1 entries, or NULL */);
+int32_t mtr_device_set_culling(mtr_device *dev, int32_t enable);
 /* Model::render (src/model.rs:299-363) with transform = view_proj (src/bin/modelviewer.rs:217-221) */
 int32_t mtr_frame_draw_model(mtr_frame *frame, mtr_model *model, const float view_proj[16]);
 int32_t mtr_frame_draw_batch(mtr_frame *frame, mtr_batch *batch, const float view_proj[16]);
@@ -175,8 +195,14 @@ void *mtr_frame_depth_devptr(mtr_frame *frame); /* f32 in HBM, row-major */
  * pack: this frame's own bins (bin % world == rank), bin-major, 16x16 RGBA8 each, into dst
  *       (mtr_shard_bytes(width,height,world) bytes) = the all-gather send buffer;
  * unpack: gathered = world such blocks in rank order -> linear RGBA8 width*height at dst. */
-size_t mtr_shard_bytes(uint32_t width, uint32_t height, uint32_t world);
+size_t mtr_shard_bytes(uint32_t width, uint32_t height, uint32_t world); /* INTERLEAVED */
+/* all-gather send size of any map = 1 KiB x the largest share of bins (0: bad arguments); pack zero-fills past a rank's own share */
+size_t mtr_shard_bytes_map(uint32_t width, uint32_t height, uint32_t world, uint32_t map, uint32_t param, const uint32_t *band_rows);
+size_t mtr_frame_shard_bytes(mtr_frame *frame); /* of this frame's map */
 int32_t mtr_frame_pack_color_shard(mtr_frame *frame, void *dst_dev, size_t dst_bytes);
+/* gathered (world blocks of mtr_frame_shard_bytes each, rank order) -> linear RGBA8 at dst_dev, by this frame's map;
+ * hip_stream NULL = the device's public stream */
+int32_t mtr_frame_unpack_color_shards_on_stream(mtr_frame *frame, const void *gathered_dev, void *dst_dev, void *hip_stream);
 int32_t mtr_device_unpack_color_shards(mtr_device *dev, const void *gathered_dev, uint32_t world,
                                        uint32_t width, uint32_t height, void *dst_dev);
 /* the same two steps on a caller-chosen hipStream_t instead of the device's public stream (the pack waits, on that

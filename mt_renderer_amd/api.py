@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_PKG, "libmtr.so")
 
 MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
 TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY, TILE_MIXED = 0, 1, 2, 3
+OWN_INTERLEAVED, OWN_BANDS, OWN_SUPERTILES = 0, 1, 2
 STAGE_NAMES = ("geom", "scan", "fill", "tile")
 
 # every symbol include/mtr.h declares (tests check that the library exports each one)
@@ -35,7 +36,8 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_synchronize", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
+    "mtr_device_synchronize", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
+    "mtr_frame_unpack_color_shards_on_stream", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
 
@@ -61,7 +63,8 @@ class _Layout(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("tris_in", C.c_uint64), ("tris_setup", C.c_uint64), ("bin_entries", C.c_uint64),
                 ("segments", C.c_uint64), ("width", C.c_uint32), ("height", C.c_uint32), ("nbins", C.c_uint32),
-                ("ndraws", C.c_uint32), ("tile_kernel", C.c_uint32), ("binning", C.c_uint32)]
+                ("ndraws", C.c_uint32), ("tile_kernel", C.c_uint32), ("binning", C.c_uint32),
+                ("chunks", C.c_uint64), ("chunks_culled", C.c_uint64), ("shard_map", C.c_uint32), ("shard_bins", C.c_uint32)]
 
     def as_dict(self) -> dict:
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -101,6 +104,11 @@ def _load() -> C.CDLL:
         "mtr_batch_destroy": (None, [vp]),
         "mtr_frame_begin": (i32, [vp, u32, u32, vp, C.c_float, C.POINTER(vp)]),
         "mtr_frame_set_shard": (i32, [vp, u32, u32]),
+        "mtr_frame_set_shard_map": (i32, [vp, u32, u32, u32, u32, vp]),
+        "mtr_device_set_culling": (i32, [vp, i32]),
+        "mtr_shard_bytes_map": (sz, [u32, u32, u32, u32, u32, vp]),
+        "mtr_frame_shard_bytes": (sz, [vp]),
+        "mtr_frame_unpack_color_shards_on_stream": (i32, [vp, vp, vp, vp]),
         "mtr_frame_draw_model": (i32, [vp, vp, vp]),
         "mtr_frame_draw_batch": (i32, [vp, vp, vp]),
         "mtr_frame_draw_instances": (i32, [vp, vp, vp, vp, sz, sz, vp]),
@@ -148,6 +156,11 @@ def _p(a: Optional[np.ndarray]):
 def _f32(a, shape=None) -> np.ndarray:
     r = np.ascontiguousarray(a, dtype=np.float32)
     return r if shape is None else r.reshape(shape)
+
+
+def shard_bytes_map(width: int, height: int, world: int, own_map: int = OWN_INTERLEAVED, param: int = 0, band_rows=None) -> int:
+    br = None if band_rows is None else np.ascontiguousarray(band_rows, dtype=np.uint32)
+    return int(lib.mtr_shard_bytes_map(width, height, world, own_map, param, _p(br)))
 
 
 def crc32(data: bytes, init: int = 0xFFFFFFFF) -> int:
@@ -199,6 +212,10 @@ class Device:
 
     def exchange_stop(self):
         self.check(lib.mtr_device_exchange_stop(self._h))
+
+    def set_culling(self, on: bool):
+        """sharded frames: skip geometry whose bounds cannot reach the rank's bins (default on)"""
+        self.check(lib.mtr_device_set_culling(self._h, 1 if on else 0))
 
     def set_tile_mode(self, mode: int):
         """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""
@@ -351,8 +368,20 @@ class Frame:
         dev.check(lib.mtr_frame_begin(dev._h, width, height, _p(c), clear_depth, C.byref(h)))
         self.dev, self._h, self.w, self.h = dev, h, width, height
 
-    def set_shard(self, rank: int, world: int):
-        self.dev.check(lib.mtr_frame_set_shard(self._h, rank, world))
+    def set_shard(self, rank: int, world: int, own_map: int = OWN_INTERLEAVED, param: int = 0, band_rows=None):
+        """render only the bins `rank` of `world` owns under the ownership map (include/mtr.h: MTR_OWN_*)"""
+        br = None if band_rows is None else np.ascontiguousarray(band_rows, dtype=np.uint32)
+        if br is not None and br.size != world + 1:
+            raise MtrError(MTR_E_INVALID, "band_rows needs world + 1 entries")
+        self.dev.check(lib.mtr_frame_set_shard_map(self._h, rank, world, own_map, param, _p(br)))
+
+    def shard_bytes(self) -> int:
+        return int(lib.mtr_frame_shard_bytes(self._h))
+
+    def unpack_color_shards(self, gathered_devptr: int, dst_devptr: int, stream: Optional[int] = None):
+        """gathered blocks (this frame's ownership map) -> linear RGBA8 at dst_devptr"""
+        self.dev.check(lib.mtr_frame_unpack_color_shards_on_stream(self._h, C.c_void_p(gathered_devptr), C.c_void_p(dst_devptr),
+                                                                   C.c_void_p(stream) if stream else None))
 
     def draw_model(self, model: Model, view_proj: np.ndarray):
         vp = _f32(view_proj, 16)

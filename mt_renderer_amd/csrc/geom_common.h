@@ -196,15 +196,115 @@ __device__ __forceinline__ VOut shade_vertex_mfma(const uint8_t* vbuf, const DPr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Geometry culling of sharded frames (multi-GPU v2).  A rank must not spend vertex work on
+// geometry that cannot reach one of its bins, and it must never skip geometry that does: the test is conservative.
+//
+// A BoneBox holds the object-space box (centre c, half extents e) of the vertices that one joint influences.  When the
+// weight bytes of every vertex sum to 255 the skinned position is a convex combination of the points P_j * (p,1) over
+// the joints j that carry weight, so every clip coordinate of every vertex lies in the union over those joints of
+//     [ v_i - r_i - m_i ,  v_i + r_i + m_i ],     v_i = (C * (c,1))_i,   r_i = sum_c |C[c][i]| * e_c,   C = M * P_j,
+// where m_i = 2^-16 * (|M| |P_j| (|c|+e, 1))_i covers the rounding of both this evaluation and of the vertex shader's own
+// fma chains (about 40 operations at 2^-24 each, relative to the same sum of magnitudes), the error of the weight sum
+// (4 * 2^-25) included.  Near-plane clipping only adds convex combinations of clip-space vertices, so the interval also
+// holds for the vertices it creates.  With w_lo > 0 the screen rectangle follows by interval division; a pixel of
+// slack and 2^-20 of the coordinate cover the divide, the viewport fma and the 1/256 snap.  Anything that cannot be
+// bounded (w_lo <= 0, NaN, weights that are not normalised) is kept.
+// ---------------------------------------------------------------------------------------------
+struct ClipBox {
+    float lo[3], hi[3];  // x, y, w
+};
+
+// interval of one box under M * [P; 0 0 0 1] (Pm: 16 floats column-major, rows 0..2 used; nullptr: identity)
+__device__ __forceinline__ ClipBox box_clip_interval(const BoneBox& b, const float* Pm, const float (&M)[16]) {
+    const float cen[3] = {b.cx, b.cy, b.cz}, ext[3] = {b.ex, b.ey, b.ez};
+    ClipBox r;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int i = t == 2 ? 3 : t;  // clip x, y, w
+        float v = 0.0f, rad = 0.0f, mag = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float C, A;
+            if (Pm) {
+                C = M[0 + i] * Pm[c * 4 + 0] + M[4 + i] * Pm[c * 4 + 1] + M[8 + i] * Pm[c * 4 + 2];
+                A = fabsf(M[0 + i]) * fabsf(Pm[c * 4 + 0]) + fabsf(M[4 + i]) * fabsf(Pm[c * 4 + 1]) + fabsf(M[8 + i]) * fabsf(Pm[c * 4 + 2]);
+                if (c == 3) { C += M[12 + i]; A += fabsf(M[12 + i]); }
+            } else {
+                C = M[c * 4 + i];
+                A = fabsf(C);
+            }
+            if (c < 3) {
+                v += C * cen[c];
+                rad += fabsf(C) * ext[c];
+                mag += A * (fabsf(cen[c]) + ext[c]);
+            } else {
+                v += C;
+                mag += A;
+            }
+        }
+        const float m = mag * 1.52587890625e-05f;  // 2^-16
+        r.lo[t] = v - rad - m;
+        r.hi[t] = v + rad + m;
+    }
+    return r;
+}
+
+__device__ __forceinline__ bool clipbox_finite(const ClipBox& r) {
+    bool ok = true;
+#pragma unroll
+    for (int t = 0; t < 3; t++) ok = ok && fabsf(r.lo[t]) < 3.0e38f && fabsf(r.hi[t]) < 3.0e38f;  // false for NaN and inf
+    return ok;
+}
+
+// May geometry whose clip coordinates lie in `u` produce a fragment in a bin of this rank?  (wave-uniform arithmetic)
+__device__ __forceinline__ bool clipbox_may_touch_rank(const ClipBox& u, const FrameBuffers& fb) {
+    const float xlo = u.lo[0], xhi = u.hi[0], ylo = u.lo[1], yhi = u.hi[1], wlo = u.lo[2], whi = u.hi[2];
+    if (!(wlo > 0.0f)) return true;  // reaches w <= 0 (or NaN): no screen bound
+    const float sx_lo = xlo >= 0.0f ? xlo / whi : xlo / wlo, sx_hi = xhi >= 0.0f ? xhi / wlo : xhi / whi;
+    const float sy_lo = ylo >= 0.0f ? ylo / whi : ylo / wlo, sy_hi = yhi >= 0.0f ? yhi / wlo : yhi / whi;
+    const float fW = (float)fb.W, fH = (float)fb.H, hw = 0.5f * fW, hh = 0.5f * fH;
+    float fx_lo = sx_lo * hw + hw, fx_hi = sx_hi * hw + hw;
+    float fy_lo = hh - sy_hi * hh, fy_hi = hh - sy_lo * hh;
+    const float mx = 1.0f + 9.5367431640625e-07f * fmaxf(fabsf(fx_lo), fabsf(fx_hi));  // 1 px + 2^-20 relative
+    const float my = 1.0f + 9.5367431640625e-07f * fmaxf(fabsf(fy_lo), fabsf(fy_hi));
+    fx_lo -= mx; fx_hi += mx; fy_lo -= my; fy_hi += my;
+    if (fx_hi < 0.0f || fx_lo > fW || fy_hi < 0.0f || fy_lo > fH) return false;  // provably off the target (NaN: kept)
+    if (!(fx_lo == fx_lo && fx_hi == fx_hi && fy_lo == fy_lo && fy_hi == fy_hi)) return true;
+    const uint32_t bx0 = (uint32_t)fminf(fmaxf(fx_lo, 0.0f), fW) >> MTR_BIN_SHIFT, by0 = (uint32_t)fminf(fmaxf(fy_lo, 0.0f), fH) >> MTR_BIN_SHIFT;
+    const uint32_t bx1 = min((uint32_t)fminf(fmaxf(fx_hi, 0.0f), fW) >> MTR_BIN_SHIFT, fb.nbx - 1u);
+    const uint32_t by1 = min((uint32_t)fminf(fmaxf(fy_hi, 0.0f), fH) >> MTR_BIN_SHIFT, fb.nby - 1u);
+    return rect_owned_any(fb.own, min(bx0, fb.nbx - 1u), min(by0, fb.nby - 1u), bx1, by1, fb.nbx);
+}
+
+// wave-wide union of the lanes' intervals (lanes that hold none pass lo = +inf, hi = -inf); every lane gets the result
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+// the same over the first 16 lanes only (DPP rotations inside row 0, then lane 0 broadcast): a chunk has <= 16 boxes
+__device__ __forceinline__ float row0_min_f32(float v) {
+#define MTR_ROR(x, c) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), c, 0xf, 0xf, false))
+    v = fminf(v, MTR_ROR(v, 0x128)); v = fminf(v, MTR_ROR(v, 0x124)); v = fminf(v, MTR_ROR(v, 0x122)); v = fminf(v, MTR_ROR(v, 0x121));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+__device__ __forceinline__ float row0_max_f32(float v) {
+    v = fmaxf(v, MTR_ROR(v, 0x128)); v = fmaxf(v, MTR_ROR(v, 0x124)); v = fmaxf(v, MTR_ROR(v, 0x122)); v = fmaxf(v, MTR_ROR(v, 0x121));
+#undef MTR_ROR
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+}
+
+// ---------------------------------------------------------------------------------------------
 // bin iteration shared by k_geom (count) and k_fill (fill): one round = up to 64 records, one per
 // lane, in record order.  Lanes whose current bin equals the wave-minimum current bin form a group;
 // f(bin, group_mask, is_member) runs once per group, groups in increasing bin order, so both
 // kernels see identical (bin, count) sequences.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool bin_owned(uint32_t bin, uint32_t rank, uint32_t world) {
-    return world <= 1 || (bin % world) == rank;
-}
-
 // wave-wide minimum as a scalar: rotate-and-min inside each row of 16 lanes with DPP (row_ror 8/4/2/1; min is
 // idempotent, so rotations give every lane its row's minimum), then four v_readlane + scalar min across the rows.
 // Six ds_bpermute shuffles did this before and were the long pole of the binning loop (~700 cycles per group).
@@ -219,10 +319,11 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 
 template <class F>
-__device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t nbx, uint32_t rank, uint32_t world, F f) {
+__device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, const FrameBuffers& fb, F f) {
+    const uint32_t nbx = fb.nbx;
     uint32_t bx = h.bx0, by = h.by0;
     // position on the first owned bin
-    while (act && !bin_owned(by * nbx + bx, rank, world)) {
+    while (act && !bin_owned(fb.own, bx, by, nbx)) {
         if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) act = false; }
     }
     for (;;) {
@@ -240,7 +341,7 @@ __device__ __forceinline__ void for_each_bin_group(RecHdr h, bool act, uint32_t 
         if (hit) {
             do {
                 if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) act = false; }
-            } while (act && !bin_owned(by * nbx + bx, rank, world));
+            } while (act && !bin_owned(fb.own, bx, by, nbx));
         }
     }
 }
@@ -277,11 +378,11 @@ __device__ __forceinline__ void walk_round(RecHdr h, bool act, uint32_t lane, FG
 
 // bins of a wide record: lane i of a 64-lane step serves bin number `i` of the rectangle (row-major)
 template <class F>
-__device__ __forceinline__ void for_each_wide_bin(RecHdr hw, uint32_t lane, uint32_t nbx, uint32_t rank, uint32_t world, F f) {
+__device__ __forceinline__ void for_each_wide_bin(RecHdr hw, uint32_t lane, const FrameBuffers& fb, F f) {
     const uint32_t w = (uint32_t)(hw.bx1 - hw.bx0 + 1), n = w * (uint32_t)(hw.by1 - hw.by0 + 1);
     for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t bin = (hw.by0 + i / w) * nbx + hw.bx0 + i % w;
-        if (bin_owned(bin, rank, world)) f(bin);
+        const uint32_t bx = hw.bx0 + i % w, by = hw.by0 + i / w;
+        if (bin_owned(fb.own, bx, by, fb.nbx)) f(by * fb.nbx + bx);
     }
 }
 
@@ -297,13 +398,13 @@ __device__ __forceinline__ void count_bins(const FrameBuffers& fb, RecHdr h, boo
     walk_round(
         h, act, lane,
         [&](bool act_sub) {
-            for_each_bin_group(h, act_sub, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool hit) {
+            for_each_bin_group(h, act_sub, fb, [&](uint32_t bin, uint64_t m, bool hit) {
                 if (hit && lane == (uint32_t)__ffsll((long long)m) - 1)
                     atomicAdd(&fb.bin_count[bin], (unsigned long long)__popcll(m) | (1ull << 32));
             });
         },
         [&](uint32_t wl) {
-            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world,
+            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb,
                               [&](uint32_t bin) { atomicAdd(&fb.bin_count[bin], 1ull | (1ull << 32)); });
         });
 }
@@ -356,14 +457,14 @@ __device__ __forceinline__ void emit_bins(const FrameBuffers& fb, RecHdr h, bool
                 }
                 ng = 0;
             };
-            for_each_bin_group(h, act_sub, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin, uint64_t m, bool) {
+            for_each_bin_group(h, act_sub, fb, [&](uint32_t bin, uint64_t m, bool) {
                 if (lane == ng) { gbin = bin; gmask = m; }
                 if (++ng == 64) flush();
             });
             flush();
         },
         [&](uint32_t wl) {
-            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin) {
+            for_each_wide_bin(hdr_of_lane(h, wl), lane, fb, [&](uint32_t bin) {
                 const unsigned long long t = atomicAdd(&fb.bin_fill[bin], 1ull | (1ull << 32));
                 put(bin, t, 1u, 0u, ord0 + wl, true, ord0 + wl);
             });
@@ -420,7 +521,7 @@ __device__ __forceinline__ void emit_bins_unordered(const FrameBuffers& fb, RecH
                 if (!__ballot(on)) break;
                 const uint32_t dx = w == 1u ? 0u : (w == 2u ? (j & 1u) : j), dy = w == 1u ? j : (w == 2u ? (j >> 1) : 0u);
                 const uint32_t bx = h.bx0 + dx, by = h.by0 + dy;
-                if (on && bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world)) {
+                if (on && bin_owned(fb.own, bx, by, fb.nbx)) {
                     ranks |= atomicAdd(&slot[(by - wy0) * 8u + (bx - wx0)], 1u) << (8u * j);
                     own |= 1u << j;
                 }
@@ -471,7 +572,7 @@ __device__ __forceinline__ void emit_bins_unordered(const FrameBuffers& fb, RecH
     };
     bool a = act && nb <= MTR_WIDE_BINS;
     uint32_t bx = h.bx0, by = h.by0;
-    while (a && !bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world)) {
+    while (a && !bin_owned(fb.own, bx, by, fb.nbx)) {
         if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) a = false; }
     }
     for (;;) {
@@ -486,14 +587,14 @@ __device__ __forceinline__ void emit_bins_unordered(const FrameBuffers& fb, RecH
         if (hit) {
             do {
                 if (++bx > h.bx1) { bx = h.bx0; if (++by > h.by1) a = false; }
-            } while (a && !bin_owned(by * fb.nbx + bx, fb.shard_rank, fb.shard_world));
+            } while (a && !bin_owned(fb.own, bx, by, fb.nbx));
         }
     }
     flush();
     // big triangles: lane = bin of the rectangle, one reservation each
     for (uint64_t mw = __ballot(nb > MTR_WIDE_BINS); mw; mw &= mw - 1) {
         const uint32_t wl = (uint32_t)__ffsll((long long)mw) - 1;
-        for_each_wide_bin(hdr_of_lane(h, wl), lane, fb.nbx, fb.shard_rank, fb.shard_world, [&](uint32_t bin) {
+        for_each_wide_bin(hdr_of_lane(h, wl), lane, fb, [&](uint32_t bin) {
             const uint32_t o = (uint32_t)atomicAdd(&fb.bin_fill[bin], 1ull | (1ull << 32));
             if (o < fb.qcap) fb.entries[bin * fb.qcap + o] = ord0 + wl;
             else atomicOr(&fb.counters[CTR_OVERFLOW], 4u);

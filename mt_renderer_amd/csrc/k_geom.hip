@@ -12,6 +12,8 @@
 // Replaces everything between `rpass.draw_indexed` (src/model.rs:357-361) and the rasteriser.
 #include "geom_common.h"
 
+#include <algorithm>
+
 namespace mtr {
 
 struct PV {  // projected vertex
@@ -59,20 +61,6 @@ struct Rec {
     RecB b;
     RecHdr h;
 };
-
-// true if some bin b of the rectangle has b % world == rank (bins are dealt round-robin in row-major order)
-__device__ __forceinline__ bool owns_any_bin(const RecHdr& h, uint32_t nbx, uint32_t rank, uint32_t world) {
-    const uint32_t w = (uint32_t)h.bx1 - h.bx0;  // width - 1
-    if (w + 1 >= world) return true;              // `world` consecutive ids hit every residue
-    const uint32_t rows = (uint32_t)h.by1 - h.by0 + 1;
-    if (rows > 8) return true;                    // tall and narrow: rare, keep (the binner filters exactly)
-    for (uint32_t y = h.by0; y <= h.by1; y++) {
-        const uint32_t first = (y * nbx + h.bx0) % world;
-        const uint32_t d = rank >= first ? rank - first : rank + world - first;
-        if (d <= w) return true;
-    }
-    return false;
-}
 
 // back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill
 __device__ __forceinline__ bool setup_tri(const PV& a, const PV& b, const PV& c, uint32_t W, uint32_t H, uint32_t mat,
@@ -136,37 +124,40 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
     __syncthreads();
 }
 
+// Conservative culling of one chunk against the rank's bins (geom_common.h): lane = one of the chunk's boxes.
+__device__ __forceinline__ bool chunk_may_touch_rank(const GeomParams& P, uint32_t inst, const DChunk& ch, bool skinned,
+                                                     const float (&M)[16], uint32_t lane) {
+    if (!P.boxes || ch.b_count == 0) return true;
+    if (skinned && (ch.b_flags & 1u)) return true;
+    const uint32_t first = skinned ? ch.b_first + 1u : ch.b_first, n = skinned ? ch.b_count - 1u : 1u;
+    if (n == 0 || n > MTR_CHUNK_MAX_BOXES) return true;
+    ClipBox cb;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { cb.lo[t] = __builtin_inff(); cb.hi[t] = -__builtin_inff(); }
+    bool bad = false;
+    if (lane < n) {
+        const BoneBox bx = P.boxes[first + lane];
+        const float* Pm = nullptr;
+        if (skinned) Pm = P.palettes + (size_t)inst * P.pal_stride + (size_t)min(bx.joint, P.npal - 1u) * 16;
+        cb = box_clip_interval(bx, Pm, M);
+        bad = !clipbox_finite(cb);
+    }
+    if (__ballot(bad)) return true;
+    ClipBox u;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { u.lo[t] = row0_min_f32(cb.lo[t]); u.hi[t] = row0_max_f32(cb.hi[t]); }
+    return clipbox_may_touch_rank(u, P.fb);
+}
+
 // MODE 0: count pass of the exact two-pass queues; 1: single-pass binning, ordered segments; 2: single-pass binning
 // for frames the visibility-key tile kernel renders (no order kept, no segments)
 template <int MODE>
-#ifndef GEOM_OCC
-#define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
-                    // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
-#endif
-__global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
-    extern __shared__ __align__(16) float s_pal[];
-    __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
-    __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t inst = blockIdx.y;
-    stage_palette(P, inst, s_pal);
-    // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of
-    // chunks so neighbouring strips (which share a vertex row) hit the same L2.  Speed only.
-    const uint32_t nblk = gridDim.x;
-    const uint32_t per = (nblk + 7) / 8;
-    const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const uint32_t c = blk * 4 + wave;
-    if (blk >= nblk || c >= P.nchunks) return;
-
-    float M[16];
-    compose_matrix(P, inst, M);
-    const DChunk ch = P.chunks[c];
-    const DPrim pr = P.prims[ch.prim];
+__device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, uint32_t c, const DChunk& ch, const DPrim& pr,
+                                           bool skinned, const float (&M)[16], const float* s_pal, RecHdr* s_hdr, uint32_t* s_slot,
+                                           uint32_t lane) {
     const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
     const uint32_t mat = P.mat_base + inst * P.mat_inst_stride + ch.prim;
     const uint32_t W = P.fb.W, H = P.fb.H;
-    const bool skinned = pr.skinnable && P.palettes && P.npal;
     const bool strip = pr.topology == 4;
 
     // ---- index fetch (Uint16, src/model.rs:307) ----
@@ -257,11 +248,11 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         }
     }
 
-    // ---- sharded frames: a rank keeps only the triangles whose bin rectangle holds one of its bins (bin % world ==
-    //      rank), so records, queue traffic and binning work shrink with the shard.  Relative order is preserved.
-    if (P.fb.shard_world > 1 && n_out) {
-        const bool k0 = owns_any_bin(r0.h, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world);
-        const bool k1 = n_out == 2 && owns_any_bin(r1.h, P.fb.nbx, P.fb.shard_rank, P.fb.shard_world);
+    // ---- sharded frames: a rank keeps only the triangles whose bin rectangle holds one of its bins, so records,
+    //      queue traffic and binning work shrink with the shard.  Relative order is preserved.
+    if (P.fb.own.world > 1 && n_out) {
+        const bool k0 = rect_owned_any(P.fb.own, r0.h.bx0, r0.h.by0, r0.h.bx1, r0.h.by1, P.fb.nbx);
+        const bool k1 = n_out == 2 && rect_owned_any(P.fb.own, r1.h.bx0, r1.h.by0, r1.h.bx1, r1.h.by1, P.fb.nbx);
         if (!k0 && k1) r0 = r1;
         n_out = (k0 ? 1u : 0u) + (k1 ? 1u : 0u);
     }
@@ -274,8 +265,10 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     // the run lives at a fixed place (chunk id * MTR_CHUNK_SLOTS): no allocator, no hot counter
     const uint32_t base = gid * MTR_CHUNK_SLOTS;
     if (lane == 0) {
-        ChunkInfo ci = {base, total};
-        P.fb.chunk_info[gid] = ci;
+        if (MODE == 0) {  // k_fill walks the runs
+            ChunkInfo ci = {base, total};
+            P.fb.chunk_info[gid] = ci;
+        }
         if (total) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], total);  // statistics only
     }
     total = __builtin_amdgcn_readfirstlane(total);
@@ -288,17 +281,17 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
     if (n_out >= 1) {
         P.fb.rec_a[base + rank] = r0.a;
-        P.fb.rec_hdr[base + rank] = r0.h;
+        if (MODE == 0) P.fb.rec_hdr[base + rank] = r0.h;  // read back by k_fill only
         if (want_b) P.fb.rec_b[base + rank] = r0.b;
-        s_hdr[wave][rank] = r0.h;
+        s_hdr[rank] = r0.h;
     }
     if (n_out == 2) {
         P.fb.rec_a[base + rank + 1] = r1.a;
-        P.fb.rec_hdr[base + rank + 1] = r1.h;
+        if (MODE == 0) P.fb.rec_hdr[base + rank + 1] = r1.h;
         if (want_b) P.fb.rec_b[base + rank + 1] = r1.b;
-        s_hdr[wave][rank + 1] = r1.h;
+        s_hdr[rank + 1] = r1.h;
     }
-    // s_hdr[wave] is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
+    // s_hdr is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -309,15 +302,120 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         const uint32_t j = round * 64 + lane;
         const bool act = j < total;
         RecHdr h = {0, 0, 0, 0};
-        if (act) h = s_hdr[wave][j];
+        if (act) h = s_hdr[j];
         if (MODE == 2) {
-            emit_bins_unordered(P.fb, h, act, gid, round, lane, s_slot[wave]);
+            emit_bins_unordered(P.fb, h, act, gid, round, lane, s_slot);
         } else if (MODE == 1) {
             emit_bins<true>(P.fb, h, act, gid, round, lane);
         } else {
             count_bins(P.fb, h, act, lane);
         }
     }
+}
+
+#ifndef GEOM_OCC
+#define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
+                    // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
+#endif
+// grid = (blocks of 4 chunks, instance slots), 256 threads: wave = one chunk of one instance.  A sharded frame first
+// tests the chunk's bounds against the rank's bins (a handful of lanes, ~150 instructions) and a workgroup whose four
+// chunks all miss leaves before the palette is even staged; a sharded batch draw walks the compacted instance list
+// k_cull_instances wrote, gridDim.y instances at a time.
+// CULL: the sharded variant (bounds test, instance list); the unsharded kernel carries none of it.
+template <int MODE, bool CULL>
+__global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
+    extern __shared__ __align__(16) float s_pal[];
+    __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
+    __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of
+    // chunks so neighbouring strips (which share a vertex row) hit the same L2.  Speed only.
+    const uint32_t nblk = gridDim.x;
+    const uint32_t per = (nblk + 7) / 8;
+    const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const uint32_t c = blk * 4 + wave;
+    if (blk >= nblk) return;  // whole workgroup
+    const bool has_chunk = c < P.nchunks;
+    DChunk ch = {};
+    DPrim pr = {};
+    if (has_chunk) { ch = P.chunks[c]; pr = P.prims[ch.prim]; }
+    const bool skinned = pr.skinnable && P.palettes && P.npal;
+    if (!CULL) {  // one instance per blockIdx.y, nothing to test
+        stage_palette(P, blockIdx.y, s_pal);  // every thread of the workgroup copies its share
+        if (!has_chunk) return;
+        float M[16];
+        compose_matrix(P, blockIdx.y, M);
+        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, skinned, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+        return;
+    }
+    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    bool first_pass = true;
+    for (uint32_t ii = blockIdx.y; ii < nlive; ii += gridDim.y) {
+        const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
+        float M[16];
+        compose_matrix(P, inst, M);
+        bool keep = has_chunk;
+        if (P.fb.own.cull) {
+            if (keep) keep = chunk_may_touch_rank(P, inst, ch, skinned, M, lane);
+            if (has_chunk && !keep && lane == 0) {
+                const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
+                if (MODE == 0) { ChunkInfo ci = {gid * MTR_CHUNK_SLOTS, 0u}; P.fb.chunk_info[gid] = ci; }
+                atomicAdd(&P.fb.counters[MTR_CTR(CTR_CULL, gid)], 1u);  // statistics only
+            }
+            // also the barrier that lets the palette of the previous pass be overwritten
+            if (!__syncthreads_or(keep ? 1 : 0)) continue;
+        } else if (!first_pass) {
+            __syncthreads();
+        }
+        first_pass = false;
+        stage_palette(P, inst, s_pal);
+        if (keep) geom_chunk<MODE>(P, inst, c, ch, pr, skinned, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+    }
+}
+
+// Instance culling of a sharded batch draw: one wave per instance, lane = per-joint box of the whole model.  The
+// instances whose bounds may reach a bin of this rank are appended to `list` (in no particular order: k_geom takes the
+// instance number from the list, so submission-order keys do not change).
+__global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
+    const uint32_t inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= P.ninst) return;
+    float M[16];
+    {
+        const float* B = P.model_mats + (size_t)inst * 16;  // M = VP * Model, the chain of compose_matrix
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) a = fmaf(P.vp[k * 4 + i], B[c * 4 + k], a);
+                M[c * 4 + i] = a;
+            }
+    }
+    ClipBox cb;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { cb.lo[t] = __builtin_inff(); cb.hi[t] = -__builtin_inff(); }
+    bool bad = false;
+    for (uint32_t i = lane; i < P.nboxes; i += 64) {
+        const BoneBox bx = P.boxes[i];
+        const float* Pm = nullptr;
+        if (bx.joint != MTR_BOX_UNSKINNED && P.palettes && P.npal) Pm = P.palettes + (size_t)inst * P.pal_stride + (size_t)min(bx.joint, P.npal - 1u) * 16;
+        const ClipBox one = box_clip_interval(bx, Pm, M);
+        bad = bad || !clipbox_finite(one);
+#pragma unroll
+        for (int t = 0; t < 3; t++) { cb.lo[t] = fminf(cb.lo[t], one.lo[t]); cb.hi[t] = fmaxf(cb.hi[t], one.hi[t]); }
+    }
+    bool keep = true;
+    if (!__ballot(bad) && P.nboxes) {
+        ClipBox u;
+#pragma unroll
+        for (int t = 0; t < 3; t++) { u.lo[t] = wave_min_f32(cb.lo[t]); u.hi[t] = wave_max_f32(cb.hi[t]); }
+        FrameBuffers fb = {};
+        fb.W = P.W; fb.H = P.H; fb.nbx = P.nbx; fb.nby = P.nby; fb.own = P.own;
+        keep = clipbox_may_touch_rank(u, fb);
+    }
+    if (keep && lane == 0) P.list[atomicAdd(P.count, 1u)] = inst;
 }
 
 // vertex stage alone (unit-parity hook: mtr_model_vertex_stage)
@@ -343,11 +441,28 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     if (p.nchunks == 0 || p.ninst == 0) return;
     uint32_t nblk = (p.nchunks + 3) / 4;
     nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
-    dim3 grid(nblk, p.ninst);
+    // a culled instance list is usually a fraction of the draw: launch instance slots for twice the rank's fair share
+    // (the kernel strides over the list, whatever its length turns out to be)
+    uint32_t ny = p.ninst;
+    if (p.inst_count && p.fb.own.world > 1) ny = std::max<uint32_t>(1u, std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world));
+    ny = std::min<uint32_t>(ny, 65535u);
+    dim3 grid(nblk, ny);
     size_t lds = (size_t)p.npal * 64;
-    if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL(mtr::k_geom<2>, grid, dim3(256), lds, s, p);
-    else if (p.fb.direct) hipLaunchKernelGGL(mtr::k_geom<1>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(mtr::k_geom<0>, grid, dim3(256), lds, s, p);
+    const bool cull = p.fb.own.cull || p.inst_list;
+    if (cull) {
+        if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
+        else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);
+    } else {
+        if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, false>), grid, dim3(256), lds, s, p);
+        else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, false>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((mtr::k_geom<0, false>), grid, dim3(256), lds, s, p);
+    }
+}
+
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t s) {
+    if (p.ninst == 0) return;
+    hipLaunchKernelGGL(mtr::k_cull_instances, dim3(p.ninst), dim3(64), 0, s, p);
 }
 
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s) {

@@ -130,13 +130,9 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
 
     const uint32_t ovf = tile_prologue(P);
     const uint32_t lane = threadIdx.x;
-    const uint32_t nbx = P.fb.nbx, nbins = nbx * P.fb.nby;
-    const uint32_t world = P.fb.shard_world ? P.fb.shard_world : 1u;
-    // XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous bin range
-    const uint32_t per = (gridDim.x + 7) / 8;
-    const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const uint32_t bin = slot * world + P.fb.shard_rank;
-    if (slot >= (nbins + world - 1 - P.fb.shard_rank) / world || bin >= nbins) return;
+    const uint32_t nbx = P.fb.nbx;
+    uint32_t bin;
+    if (!block_to_bin(P.fb, bin)) return;
     if (P.mixed && !P.bin_flag[bin]) return;  // mixed frame: k_tile_vis has rendered this bin (only opaque triangles in it)
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
 
@@ -467,9 +463,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
 }  // namespace mtr
 
 void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s) {
-    const uint32_t nbins = p.fb.nbx * p.fb.nby;
-    const uint32_t world = p.fb.shard_world ? p.fb.shard_world : 1u;
-    uint32_t mine = (nbins + world - 1 - p.fb.shard_rank) / world;
+    const uint32_t mine = p.fb.own.own_count;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
     if (textured) hipLaunchKernelGGL(mtr::k_tile<true>, dim3(grid), dim3(64), 0, s, p);

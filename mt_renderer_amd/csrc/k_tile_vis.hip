@@ -363,9 +363,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 }  // namespace mtr
 
 void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
-    const uint32_t nbins = p.fb.nbx * p.fb.nby;
-    const uint32_t world = p.fb.shard_world ? p.fb.shard_world : 1u;
-    uint32_t mine = (nbins + world - 1 - p.fb.shard_rank) / world;
+    const uint32_t mine = p.fb.own.own_count;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
     if (textured) hipLaunchKernelGGL(mtr::k_tile_vis<true>, dim3(grid), dim3(64 * VIS_WAVES), 0, s, p);

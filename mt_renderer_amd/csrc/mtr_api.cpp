@@ -59,6 +59,9 @@ struct Slot {
     uint32_t* bin_start = nullptr;
     uint32_t* seg_start = nullptr;
     uint8_t* bin_flag = nullptr;   // mixed frames: 1 = the bin holds a translucent triangle (ordered kernel's)
+    uint32_t* inst_list = nullptr;   // sharded batch draws: compacted instance lists, draw after draw
+    uint32_t* inst_count = nullptr;  // one counter per draw
+    uint32_t inst_cap = 0, draw_cap = 0;
     uint32_t bin_cap = 0;
     uint32_t* entries = nullptr;  // submission order of every (triangle, bin) pair
     Seg* segs = nullptr;
@@ -68,6 +71,18 @@ struct Slot {
     bool bin_fill_dirty = true;      // direct frames leave bin_fill zeroed (the tile kernels clean up); others do not
     std::vector<DMat> mats_uploaded;  // what `mats` currently holds: steady-state frames skip the upload
     hipStream_t stream = nullptr;     // a slot's frames are ordered by this stream: reuse needs no event
+};
+
+// Which rank owns which bin, for one (frame size, map, world) combination: host lists + their device image.
+struct OwnTable {
+    uint32_t w = 0, h = 0, map = 0, param = 0, world = 1;
+    std::vector<uint32_t> bands;  // BANDS: world + 1 bin rows
+    std::vector<uint32_t> offs;   // world + 1: rank r's bins are lists[offs[r] .. offs[r+1])
+    uint32_t stride_bins = 0;     // the largest share = bins per rank in an all-gather buffer
+    uint32_t nsx = 0, st_shift = 0;
+    uint32_t* d_lists = nullptr;       // nbins bin ids, rank after rank, each in tile-kernel order
+    uint32_t* d_src_of_bin = nullptr;  // nbins: rank * stride_bins + k
+    uint32_t refs = 0;                 // live frames that use it (submit_mu)
 };
 
 struct mtr_device {
@@ -116,6 +131,8 @@ struct mtr_device {
     std::mutex pool_mu;
     std::vector<ColorDepth> free_fb;
     std::vector<std::pair<uint64_t, uint32_t>> fb_allocated;  // (w << 32 | h) -> colour / depth sets ever allocated
+    std::vector<std::unique_ptr<OwnTable>> own_tables;  // grow-only cache (submit_mu)
+    bool cull_enabled = true;   // sharded frames cull chunks / instances against the rank's bins
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
     struct Exchange* xchg = nullptr;  // exchange thread of a sharded device (mtr_device_exchange_start)
 };
@@ -185,6 +202,16 @@ struct mtr_model {
     uint64_t ntris_visible = 0;
     bool chunks_dirty = true;
     size_t vertex_len = 0;
+    // culling bounds (multi-GPU v2), computed once at creation over every chunk of every primitive, whatever parts_disp
+    // says: chunk k of primitive p is static chunk prim_chunk_base[p] + k
+    std::vector<uint32_t> prim_chunk_base;
+    std::vector<uint32_t> cb_first, cb_count, cb_flags;  // per static chunk: its boxes in d_boxes
+    BoneBox* d_boxes = nullptr;
+    // whole-model boxes for instance culling: [0, n_inst_unskinned) what a draw without palette transforms (one box),
+    // [n_inst_unskinned, +n_inst_skinned) what a skinned draw does (the unskinnable primitives' box, then one per joint)
+    BoneBox* d_inst_boxes = nullptr;
+    uint32_t n_inst_unskinned = 0, n_inst_skinned = 0;
+    bool inst_skinned_boundable = false;  // every skinned vertex's weights sum to 255
 };
 
 struct mtr_batch {
@@ -228,6 +255,7 @@ struct mtr_frame {
     float clear_depth;
     ColorDepth fb;
     uint32_t shard_rank = 0, shard_world = 1;
+    const OwnTable* own = nullptr;  // ownership map of a sharded frame (cached in the device), nullptr: not sharded
     std::vector<Draw> draws;
     std::vector<DMat> mats_host;  // kept alive until the async upload has certainly been consumed
     bool submitted = false, waited = false, all_opaque = true, force_two_pass = false, ran_direct = false;
@@ -236,6 +264,7 @@ struct mtr_frame {
     bool have_events = false;
     float ms[MTR_STAGE_COUNT] = {};
     int slot = 0;
+    uint64_t total_chunks = 0;
     uint64_t min_entries = 0, min_segs = 0;  // queue sizes measured by a previous, overflowed attempt
     bool for_exchange = false;  // submitted through mtr_frame_submit_exchange: no public-stream consumer
     int status_idx = -1;        // this frame's word of mtr_device::status_host (set by run_frame)
@@ -371,6 +400,242 @@ int32_t report_sticky(mtr_device* d) {
     return fail(d, rc, msg);
 }
 
+// ---- ownership maps (mtr_internal.h: Ownership) ----
+bool valid_own_args(uint32_t w, uint32_t h, uint32_t world, uint32_t map, uint32_t param, const uint32_t* band_rows) {
+    if (w == 0 || h == 0 || w > 16384 || h > 16384 || world == 0 || world > 4096) return false;
+    const uint32_t nby = (h + MTR_BIN - 1) / MTR_BIN;
+    if (map == MTR_OWN_INTERLEAVED) return true;
+    if (map == MTR_OWN_SUPERTILES) return param <= 6;
+    if (map != MTR_OWN_BANDS) return false;
+    if (band_rows) {
+        if (band_rows[0] != 0 || band_rows[world] != nby) return false;
+        for (uint32_t r = 0; r < world; r++)
+            if (band_rows[r] > band_rows[r + 1]) return false;
+    }
+    return true;
+}
+
+// host lists of a map: lists = every bin, rank after rank; offs[r] = where rank r's share starts
+void build_own_lists(uint32_t w, uint32_t h, uint32_t world, uint32_t map, uint32_t param, const uint32_t* band_rows,
+                     std::vector<uint32_t>& bands, std::vector<uint32_t>& lists, std::vector<uint32_t>& offs) {
+    const uint32_t nbx = (w + MTR_BIN - 1) / MTR_BIN, nby = (h + MTR_BIN - 1) / MTR_BIN, nbins = nbx * nby;
+    bands.clear();
+    if (map == MTR_OWN_BANDS) {
+        bands.resize(world + 1);
+        for (uint32_t r = 0; r <= world; r++) bands[r] = band_rows ? band_rows[r] : (uint32_t)((uint64_t)r * nby / world);
+    }
+    std::vector<std::vector<uint32_t>> per(world);
+    if (map == MTR_OWN_BANDS) {
+        for (uint32_t r = 0; r < world; r++)
+            for (uint32_t b = bands[r] * nbx; b < bands[r + 1] * nbx; b++) per[r].push_back(b);
+    } else if (map == MTR_OWN_SUPERTILES) {
+        const uint32_t S = 1u << param, nsx = (nbx + S - 1) >> param, nsy = (nby + S - 1) >> param;
+        for (uint32_t st = 0; st < nsx * nsy; st++) {
+            const uint32_t sx = st % nsx, sy = st / nsx;
+            for (uint32_t by = sy * S; by < std::min(nby, (sy + 1) * S); by++)
+                for (uint32_t bx = sx * S; bx < std::min(nbx, (sx + 1) * S); bx++) per[st % world].push_back(by * nbx + bx);
+        }
+    } else {
+        for (uint32_t b = 0; b < nbins; b++) per[b % world].push_back(b);
+    }
+    lists.clear();
+    offs.assign(world + 1, 0);
+    for (uint32_t r = 0; r < world; r++) {
+        lists.insert(lists.end(), per[r].begin(), per[r].end());
+        offs[r + 1] = (uint32_t)lists.size();
+    }
+}
+
+uint32_t stride_of(const std::vector<uint32_t>& offs) {
+    uint32_t s = 0;
+    for (size_t r = 0; r + 1 < offs.size(); r++) s = std::max(s, offs[r + 1] - offs[r]);
+    return s;
+}
+
+// the device's cached table for a map (built and uploaded on first use); submit_mu held
+int32_t get_own_table(mtr_device* d, uint32_t w, uint32_t h, uint32_t world, uint32_t map, uint32_t param, const uint32_t* band_rows,
+                      const OwnTable** out) {
+    *out = nullptr;
+    if (!valid_own_args(w, h, world, map, param, band_rows)) return fail(d, MTR_E_INVALID, "bad ownership map arguments");
+    if (map != MTR_OWN_SUPERTILES) param = 0;
+    const uint32_t nby = (h + MTR_BIN - 1) / MTR_BIN;
+    std::vector<uint32_t> bands;
+    if (map == MTR_OWN_BANDS) {
+        bands.resize(world + 1);
+        for (uint32_t r = 0; r <= world; r++) bands[r] = band_rows ? band_rows[r] : (uint32_t)((uint64_t)r * nby / world);
+    }
+    for (auto& t : d->own_tables)
+        if (t->w == w && t->h == h && t->map == map && t->param == param && t->world == world && t->bands == bands) { *out = t.get(); return MTR_OK; }
+    if (d->own_tables.size() >= 64) {  // a host that keeps changing the map: drop the tables no live frame uses
+        int32_t rc = drain_all(d);        // (nothing in flight may still read them)
+        if (rc) return rc;
+        size_t keep = 0;
+        for (auto& t : d->own_tables) {
+            if (t->refs) { d->own_tables[keep++] = std::move(t); continue; }
+            (void)hipFree(t->d_lists); (void)hipFree(t->d_src_of_bin);
+        }
+        d->own_tables.resize(keep);
+    }
+    auto t = std::make_unique<OwnTable>();
+    t->w = w; t->h = h; t->map = map; t->param = param; t->world = world;
+    std::vector<uint32_t> lists;
+    build_own_lists(w, h, world, map, param, band_rows, t->bands, lists, t->offs);
+    t->stride_bins = stride_of(t->offs);
+    t->st_shift = param; t->nsx = (((w + MTR_BIN - 1) / MTR_BIN) + (1u << param) - 1) >> param;
+    std::vector<uint32_t> src(lists.size());
+    for (uint32_t r = 0; r < world; r++)
+        for (uint32_t k = t->offs[r]; k < t->offs[r + 1]; k++) src[lists[k]] = r * t->stride_bins + (k - t->offs[r]);
+    int32_t rc = dev_alloc(d, &t->d_lists, lists.size());
+    if (!rc) rc = dev_alloc(d, &t->d_src_of_bin, src.size());
+    if (rc) return rc;
+    HIPCHK(d, hipMemcpy(t->d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(d, hipMemcpy(t->d_src_of_bin, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    *out = t.get();
+    d->own_tables.push_back(std::move(t));
+    return MTR_OK;
+}
+
+// ---- host mirror of the position decode (csrc/geom_common.h: decode_elem), for the culling bounds ----
+float h_half(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, ex = (h >> 10) & 0x1f, man = h & 0x3ff;
+    uint32_t bits;
+    if (ex == 0) {
+        if (man == 0) bits = sign;
+        else {  // subnormal: man * 2^-24
+            float f = (float)man * 5.9604644775390625e-08f;
+            memcpy(&bits, &f, 4);
+            bits |= sign;
+        }
+    } else if (ex == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((ex + 112) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+float h_snorm16(uint16_t v) { float f = (float)(int16_t)v / 32767.0f; return f < -1.0f ? -1.0f : f; }
+float h_snorm8(uint8_t v) { float f = (float)(int8_t)v / 127.0f; return f < -1.0f ? -1.0f : f; }
+float h_unorm8(uint8_t v) { return (float)v / 255.0f; }
+uint16_t h_ld16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+void decode_pos_host(uint32_t fmt, uint32_t cnt, const uint8_t* p, float (&o)[3]) {
+    o[0] = o[1] = o[2] = 0.0f;
+    switch (fmt) {
+    case MTR_IEF_U8N: case MTR_IEF_U8NL:
+        o[0] = h_unorm8(p[0]); o[1] = h_unorm8(p[1]);
+        if (!(fmt == MTR_IEF_U8N && cnt == 1)) o[2] = h_unorm8(p[2]);
+        break;
+    case MTR_IEF_S8N:
+        o[0] = h_snorm8(p[0]); o[1] = h_snorm8(p[1]);
+        if (cnt != 1) o[2] = h_snorm8(p[2]);
+        break;
+    case MTR_IEF_S16N:
+        o[0] = h_snorm16(h_ld16(p)); o[1] = h_snorm16(h_ld16(p + 2));
+        if (cnt == 3) o[2] = h_snorm16(h_ld16(p + 4));
+        break;
+    case MTR_IEF_F16:
+        o[0] = h_half(h_ld16(p)); o[1] = h_half(h_ld16(p + 2));
+        break;
+    case MTR_IEF_F32:
+        memcpy(&o[0], p, 4); memcpy(&o[1], p + 4, 4); memcpy(&o[2], p + 8, 4);
+        break;
+    default: break;
+    }
+}
+
+struct BoxAcc {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    bool any = false, bad = false;
+    void add(const float (&p)[3]) {
+        for (int k = 0; k < 3; k++) {
+            if (!(std::fabs(p[k]) < 3.0e38f)) bad = true;  // NaN / inf position: the box cannot hold it
+            lo[k] = std::min(lo[k], (double)p[k]); hi[k] = std::max(hi[k], (double)p[k]);
+        }
+        any = true;
+    }
+    void merge(const BoxAcc& o) {
+        if (!o.any) return;
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], o.lo[k]); hi[k] = std::max(hi[k], o.hi[k]); }
+        any = true; bad = bad || o.bad;
+    }
+    BoneBox box(uint32_t joint) const {
+        BoneBox b{};
+        float* c = &b.cx; float* e = &b.ex;
+        for (int k = 0; k < 3; k++) {
+            const float cf = (float)((lo[k] + hi[k]) * 0.5);
+            const double ext = std::max(hi[k] - (double)cf, (double)cf - lo[k]);
+            c[k] = cf;
+            e[k] = std::nextafter((float)ext, INFINITY);  // rounded up
+            if (bad) e[k] = INFINITY;                      // the test sees a non-finite interval and keeps the geometry
+        }
+        b.joint = joint;
+        return b;
+    }
+};
+
+// Chunk and whole-model bounds of a new model (vertex bytes still on the host).  boxes: the d_boxes image.
+void build_bounds(mtr_model* m, const uint8_t* vbuf, std::vector<BoneBox>& boxes, std::vector<BoneBox>& inst_boxes) {
+    const size_t nprims = m->prims.size();
+    m->prim_chunk_base.assign(nprims + 1, 0);
+    for (size_t p = 0; p < nprims; p++)
+        m->prim_chunk_base[p + 1] = m->prim_chunk_base[p] + (m->prims[p].index_num + MTR_CHUNK_NEW - 1) / MTR_CHUNK_NEW;
+    const size_t nstatic = m->prim_chunk_base[nprims];
+    m->cb_first.assign(nstatic, 0); m->cb_count.assign(nstatic, 0); m->cb_flags.assign(nstatic, 0);
+    BoxAcc all_unskinned, rigid_part;   // every vertex / the vertices of primitives that cannot be skinned
+    std::vector<BoxAcc> joint_acc(256);
+    bool weights_ok = true;
+    struct JA { uint32_t joint; BoxAcc acc; };
+    std::vector<JA> ja;
+    for (size_t p = 0; p < nprims; p++) {
+        const DPrim& pr = m->prims[p];
+        const uint8_t* vb = vbuf + pr.vertex_base;
+        for (uint32_t start = 0, k = 0; start < pr.index_num; start += MTR_CHUNK_NEW, k++) {
+            const size_t sc = m->prim_chunk_base[p] + k;
+            BoxAcc whole;
+            ja.clear();
+            uint32_t flags = 0;
+            const uint32_t lo = start >= 2 ? start - 2 : 0, hi = std::min(pr.index_num, start + MTR_CHUNK_NEW);
+            for (uint32_t q = lo; q < hi; q++) {
+                const uint32_t idx = m->indices[pr.index_ofs + q];
+                if (pr.topology == 4 && idx == 0xFFFFu) continue;
+                const uint32_t vid = idx + pr.index_base;
+                if (vid >= pr.vertex_num) continue;
+                const uint8_t* vp = vb + (size_t)vid * pr.stride;
+                float pos[3];
+                decode_pos_host(pr.pos_fmt, pr.pos_cnt, vp + pr.pos_off, pos);
+                whole.add(pos);
+                if (!pr.skinnable) continue;
+                const uint8_t* jp = vp + pr.joint_off; const uint8_t* wp = vp + pr.weight_off;
+                if ((uint32_t)wp[0] + wp[1] + wp[2] + wp[3] != 255u) { flags |= 1u; weights_ok = false; }
+                for (int t = 0; t < 4; t++) {
+                    if (wp[t] == 0) continue;  // contributes exactly nothing to the blend
+                    joint_acc[jp[t]].add(pos);
+                    size_t e = 0;
+                    while (e < ja.size() && ja[e].joint != jp[t]) e++;
+                    if (e == ja.size()) ja.push_back({jp[t], BoxAcc()});
+                    ja[e].acc.add(pos);
+                }
+            }
+            all_unskinned.merge(whole);
+            if (!pr.skinnable) rigid_part.merge(whole);
+            if (!whole.any) continue;  // no vertex: nothing to bound (the chunk is kept, it has no triangle anyway)
+            if (ja.size() > MTR_CHUNK_MAX_BOXES) { flags |= 1u; ja.clear(); }
+            m->cb_first[sc] = (uint32_t)boxes.size();
+            m->cb_count[sc] = 1u + (uint32_t)ja.size();
+            m->cb_flags[sc] = flags;
+            boxes.push_back(whole.box(MTR_BOX_UNSKINNED));
+            for (const JA& e : ja) boxes.push_back(e.acc.box(e.joint));
+        }
+    }
+    inst_boxes.clear();
+    if (all_unskinned.any) inst_boxes.push_back(all_unskinned.box(MTR_BOX_UNSKINNED));
+    m->n_inst_unskinned = (uint32_t)inst_boxes.size();
+    if (rigid_part.any) inst_boxes.push_back(rigid_part.box(MTR_BOX_UNSKINNED));
+    for (uint32_t j = 0; j < 256; j++)
+        if (joint_acc[j].any) inst_boxes.push_back(joint_acc[j].box(j));
+    m->n_inst_skinned = (uint32_t)inst_boxes.size() - m->n_inst_unskinned;
+    m->inst_skinned_boundable = weights_ok;
+}
+
 void rebuild_chunks(mtr_model* m) {
     m->chunks.clear();
     m->ntris_visible = 0;
@@ -394,6 +659,8 @@ void rebuild_chunks(mtr_model* m) {
                 }
             }
             c.ntris = nt;
+            const size_t sc = m->prim_chunk_base[p] + start / MTR_CHUNK_NEW;
+            c.b_first = m->cb_first[sc]; c.b_count = m->cb_count[sc]; c.b_flags = m->cb_flags[sc]; c.pad = 0;
             m->ntris_visible += nt;
             m->chunks.push_back(c);
         }
@@ -460,6 +727,10 @@ void mtr_device_destroy(mtr_device* d) {
     for (auto& g : d->garbage) (void)hipFree(g.p);
     if (d->s_copy) (void)hipStreamDestroy(d->s_copy);
     if (d->cube) mtr_model_destroy(d->cube);
+    for (auto& t : d->own_tables) {
+        if (t->d_lists) (void)hipFree(t->d_lists);
+        if (t->d_src_of_bin) (void)hipFree(t->d_src_of_bin);
+    }
     for (auto& f : d->free_fb) {
         (void)hipFree(f.color);
         (void)hipFree(f.depth);
@@ -468,7 +739,7 @@ void mtr_device_destroy(mtr_device* d) {
     }
     for (Slot& sl : d->slots) {
         void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
-                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag};
+                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -680,6 +951,14 @@ int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_le
     if ((rc = dev_alloc(d, &m->d_vbuf, vertex_len + 16))) return rc;
     if ((rc = dev_alloc(d, &m->d_ibuf, index_num + 2))) return rc;
     if ((rc = dev_alloc(d, &m->d_prims, nprims))) return rc;
+    {
+        std::vector<BoneBox> boxes, inst_boxes;
+        build_bounds(m.get(), static_cast<const uint8_t*>(vertex_buf), boxes, inst_boxes);
+        if ((rc = dev_alloc(d, &m->d_boxes, boxes.size()))) return rc;
+        if ((rc = dev_alloc(d, &m->d_inst_boxes, inst_boxes.size()))) return rc;
+        if (!boxes.empty()) HIPCHK(d, hipMemcpy(m->d_boxes, boxes.data(), boxes.size() * sizeof(BoneBox), hipMemcpyHostToDevice));
+        if (!inst_boxes.empty()) HIPCHK(d, hipMemcpy(m->d_inst_boxes, inst_boxes.data(), inst_boxes.size() * sizeof(BoneBox), hipMemcpyHostToDevice));
+    }
     HIPCHK(d, hipMemcpyAsync(m->d_vbuf, vertex_buf, vertex_len, hipMemcpyHostToDevice, d->stream));
     HIPCHK(d, hipMemcpyAsync(m->d_ibuf, index_buf, index_num * 2, hipMemcpyHostToDevice, d->stream));
     HIPCHK(d, hipMemcpyAsync(m->d_prims, m->prims.data(), nprims * sizeof(DPrim), hipMemcpyHostToDevice, d->stream));
@@ -696,7 +975,7 @@ void mtr_model_destroy(mtr_model* m) {
         if (pb.d) (void)hipFree(pb.d);
         if (pb.ready) (void)hipEventDestroy(pb.ready);
     }
-    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks};
+    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks, m->d_boxes, m->d_inst_boxes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -874,6 +1153,10 @@ void mtr_frame_destroy(mtr_frame* f) {
     if (f->have_events)
         for (auto& e : f->ev)
             if (e) (void)hipEventDestroy(e);
+    if (f->own) {
+        std::lock_guard<std::mutex> g(d->submit_mu);
+        const_cast<OwnTable*>(f->own)->refs--;
+    }
     for (Draw& dr : f->draws)  // drawn, never submitted
         if (dr.pal_pinned && dr.pal_slot >= 0 && (size_t)dr.pal_slot < dr.model->pal_ring.size()) {
             std::lock_guard<std::mutex> g(d->submit_mu);
@@ -893,10 +1176,31 @@ void mtr_frame_destroy(mtr_frame* f) {
     delete f;
 }
 
-int32_t mtr_frame_set_shard(mtr_frame* f, uint32_t rank, uint32_t world) {
+int32_t mtr_frame_set_shard_map(mtr_frame* f, uint32_t rank, uint32_t world, uint32_t map, uint32_t param, const uint32_t* band_rows) {
     if (!f) return MTR_E_INVALID;
-    if (world == 0 || rank >= world) return fail(f->dev, MTR_E_INVALID, "bad shard rank/world");
-    f->shard_rank = rank; f->shard_world = world;
+    mtr_device* d = f->dev;
+    if (world == 0 || rank >= world) return fail(d, MTR_E_INVALID, "bad shard rank/world");
+    if (f->submitted) return fail(d, MTR_E_INVALID, "frame already submitted");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    const OwnTable* t = nullptr;
+    {
+        std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+        if ((rc = get_own_table(d, f->w, f->h, world, map, param, band_rows, &t))) return rc;
+        if (f->own) const_cast<OwnTable*>(f->own)->refs--;
+        const_cast<OwnTable*>(t)->refs++;
+    }
+    f->shard_rank = rank; f->shard_world = world; f->own = t;
+    return MTR_OK;
+}
+
+int32_t mtr_frame_set_shard(mtr_frame* f, uint32_t rank, uint32_t world) {
+    return mtr_frame_set_shard_map(f, rank, world, MTR_OWN_INTERLEAVED, 0, nullptr);
+}
+
+int32_t mtr_device_set_culling(mtr_device* d, int32_t enable) {
+    if (!d) return MTR_E_INVALID;
+    d->cull_enabled = enable != 0;
     return MTR_OK;
 }
 
@@ -1135,7 +1439,16 @@ static int32_t run_frame(mtr_frame* f) {
     fb.entries = sl.entries; fb.segs = sl.segs; fb.counters = f->fb.live();
     fb.rec_cap = sl.rec_cap; fb.entry_cap = sl.entry_cap; fb.seg_cap = sl.seg_cap;
     fb.W = f->w; fb.H = f->h; fb.nbx = nbx; fb.nby = nby;
-    fb.shard_rank = f->shard_rank; fb.shard_world = f->shard_world;
+    fb.own.map = MTR_OWN_INTERLEAVED; fb.own.rank = 0; fb.own.world = 1; fb.own.own_count = nbins; fb.own.own_list = nullptr;
+    if (f->own && f->shard_world > 1) {
+        const OwnTable& t = *f->own;
+        fb.own.map = t.map; fb.own.rank = f->shard_rank; fb.own.world = f->shard_world;
+        if (t.map == MTR_OWN_BANDS) { fb.own.y0 = t.bands[f->shard_rank]; fb.own.y1 = t.bands[f->shard_rank + 1]; }
+        fb.own.st_shift = t.st_shift; fb.own.nsx = t.nsx;
+        fb.own.own_count = t.offs[f->shard_rank + 1] - t.offs[f->shard_rank];
+        fb.own.own_list = t.d_lists + t.offs[f->shard_rank];
+        fb.own.cull = d->cull_enabled ? 1u : 0u;
+    }
     fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
     // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a
     // per-pixel (min z, latest) reduction and the visibility-key kernel applies; otherwise blend order matters
@@ -1160,6 +1473,30 @@ static int32_t run_frame(mtr_frame* f) {
         HIPCHK(d, hipMemsetAsync(sl.bin_fill, 0, (size_t)sl.bin_cap * sizeof(unsigned long long), sg));
         sl.bin_fill_dirty = false;
     }
+    // sharded batch draws: cull the instances against this rank's bins first (k_cull_instances -> compacted lists)
+    std::vector<uint32_t> inst_off(f->draws.size(), 0xFFFFFFFFu);
+    if (fb.own.cull) {
+        uint64_t ninst_total = 0;
+        for (size_t di = 0; di < f->draws.size(); di++) {
+            const Draw& dr = f->draws[di];
+            if (!dr.d_model_mats) continue;  // a single model: chunk culling only
+            const mtr_model* m = dr.model;
+            const bool sk = dr.d_palettes && dr.npal;
+            if (sk ? (!m->inst_skinned_boundable || m->n_inst_skinned == 0) : (m->n_inst_unskinned == 0)) continue;
+            inst_off[di] = (uint32_t)ninst_total;
+            ninst_total += dr.ninst;
+        }
+        if (ninst_total) {
+            if (ninst_total > sl.inst_cap || f->draws.size() > sl.draw_cap || !sl.inst_list) {
+                HIPCHK(d, hipStreamSynchronize(sl.stream));
+                if ((rc = dev_grow(d, &sl.inst_list, &sl.inst_cap, ninst_total))) return rc;
+                if ((rc = dev_grow(d, &sl.inst_count, &sl.draw_cap, std::max<size_t>(f->draws.size(), 16)))) return rc;
+            }
+            HIPCHK(d, hipMemsetAsync(sl.inst_count, 0, f->draws.size() * sizeof(uint32_t), sg));
+            // the exact two-pass fill walks every chunk's run descriptor: the chunks of culled instances write none
+            if (!fb.direct) HIPCHK(d, hipMemsetAsync(sl.chunk_info, 0, total_chunks * sizeof(ChunkInfo), sg));
+        }
+    }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[0], sg));
     uint32_t chunk_base = 0;
     for (size_t di = 0; di < f->draws.size(); di++) {
@@ -1167,6 +1504,7 @@ static int32_t run_frame(mtr_frame* f) {
         mtr_model* m = dr.model;
         GeomParams gp{};
         gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = m->d_chunks;
+        gp.boxes = m->d_boxes;
         gp.nchunks = (uint32_t)m->chunks.size(); gp.ninst = dr.ninst;
         if (dr.batch) { dr.batch->last_frame = this_frame; dr.batch->used = true; }
         if (dr.pal_ready) {  // uploads of a model palette (ring) or of a batch, made on the copy stream
@@ -1184,6 +1522,17 @@ static int32_t run_frame(mtr_frame* f) {
         gp.chunk_base = chunk_base; gp.mat_base = mat_base[di]; gp.mat_inst_stride = mat_stride[di];
         gp.fb = fb;
         gp.mats = sl.mats;
+        if (inst_off[di] != 0xFFFFFFFFu) {
+            CullParams cp{};
+            const bool sk = dr.d_palettes && dr.npal;
+            cp.boxes = m->d_inst_boxes + (sk ? m->n_inst_unskinned : 0); cp.nboxes = sk ? m->n_inst_skinned : m->n_inst_unskinned;
+            cp.ninst = dr.ninst; cp.model_mats = dr.d_model_mats; cp.palettes = gp.palettes; cp.npal = gp.npal; cp.pal_stride = gp.pal_stride;
+            memcpy(cp.vp, dr.vp, sizeof cp.vp);
+            cp.W = f->w; cp.H = f->h; cp.nbx = nbx; cp.nby = nby; cp.own = fb.own;
+            cp.list = sl.inst_list + inst_off[di]; cp.count = sl.inst_count + di;
+            mtr_launch_cull_instances(cp, sg);
+            gp.inst_list = cp.list; gp.inst_count = cp.count;
+        }
         mtr_launch_geom(gp, sg);
         chunk_base += gp.nchunks * dr.ninst;
     }
@@ -1204,11 +1553,13 @@ static int32_t run_frame(mtr_frame* f) {
     const bool mixed = !use_vis && d->tile_mode == MTR_TILE_AUTO && any_opaque;
     tp.bin_flag = sl.bin_flag; tp.mixed = mixed ? 1u : 0u;
     tp.zero_next = f->fb.other();
-    f->fb.next_zeroed = true;
+    f->fb.next_zeroed = fb.own.own_count != 0;  // a rank without a bin launches no tile workgroup
     tp.host_status = d->status_dev + sidx;
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
     if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
     if (!use_vis) mtr_launch_tile(tp, any_textured, st);
+    // a rank without a bin launches no tile workgroup: nobody else would publish the (clean) status
+    if (fb.own.own_count == 0) __atomic_store_n(&d->status_host[sidx], 0x80000000u, __ATOMIC_RELEASE);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
     HIPCHK(d, hipEventRecord(f->fb.done, st));
     HIPCHK(d, hipEventRecord(ring, st));
@@ -1223,6 +1574,7 @@ static int32_t run_frame(mtr_frame* f) {
         f->stats.binning = f->ran_direct ? 1u : 2u;
     }
     f->stats.tris_in = tris_in;
+    f->total_chunks = total_chunks;
     f->stats.width = f->w; f->stats.height = f->h; f->stats.nbins = nbins; f->stats.ndraws = (uint32_t)f->draws.size();
     return MTR_OK;
 }
@@ -1325,6 +1677,11 @@ static int32_t fetch_stats(mtr_frame* f) {
         }
     }
     f->stats.binning = f->ran_direct ? 1u : 2u;
+    f->stats.chunks = f->total_chunks;
+    f->stats.chunks_culled = 0;
+    for (int k = 0; k < CTR_NSHARDS; k++) f->stats.chunks_culled += ctr[MTR_CTR(CTR_CULL, k)];
+    f->stats.shard_map = f->own ? f->own->map : 0u;
+    f->stats.shard_bins = f->own ? f->own->offs[f->shard_rank + 1] - f->own->offs[f->shard_rank] : f->stats.nbins;
     f->stats_valid = true;
     return MTR_OK;
 }
@@ -1367,15 +1724,40 @@ size_t mtr_shard_bytes(uint32_t w, uint32_t h, uint32_t world) {
     return (nbins + world - 1) / world * (MTR_BIN * MTR_BIN * 4);
 }
 
+size_t mtr_shard_bytes_map(uint32_t w, uint32_t h, uint32_t world, uint32_t map, uint32_t param, const uint32_t* band_rows) {
+    if (!valid_own_args(w, h, world, map, param, band_rows)) return 0;
+    std::vector<uint32_t> bands, lists, offs;
+    build_own_lists(w, h, world, map, map == MTR_OWN_SUPERTILES ? param : 0, band_rows, bands, lists, offs);
+    return (size_t)stride_of(offs) * (MTR_BIN * MTR_BIN * 4);
+}
+
+// the frame's ownership table; an unsharded frame packs / unpacks as a world of one
+static int32_t frame_table(mtr_frame* f, const OwnTable** t) {
+    *t = f->own;
+    if (*t) return MTR_OK;
+    std::lock_guard<std::mutex> submit_lock(f->dev->submit_mu);
+    return get_own_table(f->dev, f->w, f->h, 1, MTR_OWN_INTERLEAVED, 0, nullptr, t);
+}
+
+size_t mtr_frame_shard_bytes(mtr_frame* f) {
+    if (!f) return 0;
+    if (!f->own) return mtr_shard_bytes(f->w, f->h, 1);
+    return (size_t)f->own->stride_bins * (MTR_BIN * MTR_BIN * 4);
+}
+
 static int32_t pack_shard_on(mtr_frame* f, void* dst_dev, size_t dst_bytes, hipStream_t s, bool wait_frame) {
     if (!f || !dst_dev) return MTR_E_INVALID;
     mtr_device* d = f->dev;
     if (!f->submitted) return fail(d, MTR_E_INVALID, "frame not submitted");
-    if (dst_bytes < mtr_shard_bytes(f->w, f->h, f->shard_world)) return fail(d, MTR_E_INVALID, "shard buffer too small");
+    if (dst_bytes < mtr_frame_shard_bytes(f)) return fail(d, MTR_E_INVALID, "shard buffer too small");
     int32_t rc = set_device(d);
     if (rc) return rc;
+    const OwnTable* t = nullptr;
+    if ((rc = frame_table(f, &t))) return rc;
     if (wait_frame) HIPCHK(d, hipStreamWaitEvent(s, f->fb.done, 0));  // the public stream already waits for every frame
-    mtr_launch_pack_shard(f->fb.color, static_cast<uint8_t*>(dst_dev), f->w, f->h, f->shard_rank, f->shard_world, s);
+    const uint32_t r = f->own ? f->shard_rank : 0;
+    mtr_launch_pack_shard(f->fb.color, static_cast<uint8_t*>(dst_dev), f->w, f->h, t->d_lists + t->offs[r], t->offs[r + 1] - t->offs[r],
+                          t->stride_bins, s);
     HIPCHK(d, hipGetLastError());
     // the colour buffer now has a reader after the tile kernel: whoever recycles it (the frame may be destroyed at
     // once) must wait for the pack too, so the buffer's completion event moves behind it
@@ -1391,14 +1773,23 @@ int32_t mtr_frame_pack_color_shard_on_stream(mtr_frame* f, void* dst_dev, size_t
     return pack_shard_on(f, dst_dev, dst_bytes, reinterpret_cast<hipStream_t>(hip_stream), true);
 }
 
+static int32_t unpack_table_on(mtr_device* d, const OwnTable* t, const void* gathered_dev, void* dst_dev, hipStream_t s) {
+    mtr_launch_unpack_shards(static_cast<const uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev), t->w, t->h, t->d_src_of_bin, s);
+    HIPCHK(d, hipGetLastError());
+    return MTR_OK;
+}
+
 static int32_t unpack_shards_on(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h, void* dst_dev, hipStream_t s) {
     if (!d || !gathered_dev || !dst_dev) return MTR_E_INVALID;
     if (world == 0 || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad unpack arguments");
     int32_t rc = set_device(d);
     if (rc) return rc;
-    mtr_launch_unpack_shards(static_cast<const uint8_t*>(gathered_dev), static_cast<uint8_t*>(dst_dev), w, h, world, s);
-    HIPCHK(d, hipGetLastError());
-    return MTR_OK;
+    const OwnTable* t = nullptr;
+    {
+        std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+        if ((rc = get_own_table(d, w, h, world, MTR_OWN_INTERLEAVED, 0, nullptr, &t))) return rc;
+    }
+    return unpack_table_on(d, t, gathered_dev, dst_dev, s);
 }
 
 int32_t mtr_device_unpack_color_shards(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h,
@@ -1409,6 +1800,16 @@ int32_t mtr_device_unpack_color_shards(mtr_device* d, const void* gathered_dev, 
 int32_t mtr_device_unpack_color_shards_on_stream(mtr_device* d, const void* gathered_dev, uint32_t world, uint32_t w, uint32_t h,
                                                  void* dst_dev, void* hip_stream) {
     return unpack_shards_on(d, gathered_dev, world, w, h, dst_dev, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int32_t mtr_frame_unpack_color_shards_on_stream(mtr_frame* f, const void* gathered_dev, void* dst_dev, void* hip_stream) {
+    if (!f || !gathered_dev || !dst_dev) return MTR_E_INVALID;
+    mtr_device* d = f->dev;
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    const OwnTable* t = nullptr;
+    if ((rc = frame_table(f, &t))) return rc;
+    return unpack_table_on(d, t, gathered_dev, dst_dev, hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->stream);
 }
 
 int32_t mtr_frame_get_stats(mtr_frame* f, mtr_frame_stats* out) {
@@ -1512,7 +1913,7 @@ static void exchange_main(mtr_device* d, Exchange* x) {
             // in the normal case this does not wait for the frame to finish.
             rc = settle_frame(f, false);
             // every rank sends exactly its shard of THIS frame: the unpack derives the per-rank stride from the frame size
-            const size_t count = mtr_shard_bytes(f->w, f->h, x->world);
+            const size_t count = mtr_frame_shard_bytes(f);
             if (rc == MTR_OK) rc = mtr_frame_pack_color_shard_on_stream(f, ln.send, count, ln.stream);
             if (rc != MTR_OK) {
                 { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
@@ -1521,7 +1922,7 @@ static void exchange_main(mtr_device* d, Exchange* x) {
                 if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
             }
             if (rc == MTR_OK) {
-                rc = mtr_device_unpack_color_shards_on_stream(d, ln.gathered, x->world, f->w, f->h, ln.dst, ln.stream);
+                rc = mtr_frame_unpack_color_shards_on_stream(f, ln.gathered, ln.dst, ln.stream);
                 if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
             }
         }
@@ -1574,7 +1975,7 @@ int32_t mtr_frame_submit_exchange(mtr_frame* f) {
     Exchange* x = d->xchg;
     if (!x) return fail(d, MTR_E_INVALID, "no exchange thread (mtr_device_exchange_start)");
     if (f->shard_world != x->world) return fail(d, MTR_E_INVALID, "frame shard world differs from the exchange's");
-    if (x->send_bytes < mtr_shard_bytes(f->w, f->h, x->world)) return fail(d, MTR_E_INVALID, "exchange send buffer too small");
+    if (x->send_bytes < mtr_frame_shard_bytes(f)) return fail(d, MTR_E_INVALID, "exchange send buffer too small");
     if (f->waited) f->flags_checked = true;
     if (!f->submitted) {
         f->for_exchange = true;  // its only consumer is the exchange thread, which waits for the frame on its own stream

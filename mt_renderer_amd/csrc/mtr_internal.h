@@ -39,7 +39,21 @@ struct DChunk {
     uint32_t start;     // first strip position whose triangle this chunk owns
     uint32_t q_before;  // strip: consecutive non-restart indices right before position start-2
     uint32_t ntris;     // input triangles completed inside this chunk (statistics)
+    uint32_t b_first;   // object-space bounds of the chunk's vertices: bounds[b_first] is the box of all of them (what an
+    uint32_t b_count;   // unskinned draw transforms), bounds[b_first + 1 ..) one box per joint that carries weight; 0: none
+    uint32_t b_flags;   // bit0: the skinned position is not a convex combination (weights do not sum to 255, or too many
+    uint32_t pad;       //       joints for the table): never culled when skinned
 };
+
+// object-space box of the vertices one joint influences inside one chunk (or of a whole model: instance culling)
+struct BoneBox {
+    float cx, cy, cz;   // centre
+    float ex, ey, ez;   // half extents, rounded up
+    uint32_t joint;     // raw joint index (clamped to the palette like the vertex shader does), 0xFFFFFFFF: unskinned
+    uint32_t pad;
+};
+#define MTR_BOX_UNSKINNED 0xFFFFFFFFu
+#define MTR_CHUNK_MAX_BOXES 16
 
 struct DMat {            // one per (draw, [instance,] primitive)
     uint32_t shader;     // MTR_SH_*
@@ -76,12 +90,56 @@ struct Seg {             // 16 B
     uint32_t pad;
 };
 
+// Ownership of the 16x16 bins of a sharded frame (multi-GPU, one rank per GPU).  The host picks the map per frame:
+//   INTERLEAVED  bin b (row-major) belongs to rank b % world: the finest balance, but every object touches every rank;
+//   BANDS        rank r owns the bin rows [band[r], band[r+1]): an object touches the few ranks whose band it crosses;
+//   SUPERTILES   squares of (1 << st_shift)^2 bins dealt round-robin in row-major order.
+// own_list: this rank's bins in the order the tile kernels take them (nullptr when the frame is not sharded).
+#ifndef MTR_H
+enum { MTR_OWN_INTERLEAVED = 0, MTR_OWN_BANDS = 1, MTR_OWN_SUPERTILES = 2 };  // include/mtr.h has the same
+#endif
+struct Ownership {
+    uint32_t map, rank, world;
+    uint32_t y0, y1;          // BANDS: this rank's bin rows [y0, y1)
+    uint32_t st_shift, nsx;   // SUPERTILES: log2 edge in bins, super-tiles per row
+    uint32_t own_count;       // bins of this rank (not sharded: every bin)
+    const uint32_t* own_list;
+    uint32_t cull;            // geometry waves test their chunk's bounds against the map before any vertex work
+    uint32_t pad;
+};
+
+__device__ __forceinline__ bool bin_owned(const Ownership& o, uint32_t bx, uint32_t by, uint32_t nbx) {
+    if (o.world <= 1) return true;
+    if (o.map == MTR_OWN_BANDS) return by >= o.y0 && by < o.y1;
+    if (o.map == MTR_OWN_SUPERTILES) return ((by >> o.st_shift) * o.nsx + (bx >> o.st_shift)) % o.world == o.rank;
+    return (by * nbx + bx) % o.world == o.rank;
+}
+
+// true if some bin of the inclusive rectangle belongs to the rank; may say true for a rectangle that holds none (the
+// binner filters bin by bin), never false for one that does
+__device__ __forceinline__ bool rect_owned_any(const Ownership& o, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1, uint32_t nbx) {
+    if (o.world <= 1) return true;
+    if (o.map == MTR_OWN_BANDS) return by1 >= o.y0 && by0 < o.y1 && o.y0 < o.y1;
+    uint32_t x0 = bx0, x1 = bx1, y0 = by0, y1 = by1, pitch = nbx;
+    if (o.map == MTR_OWN_SUPERTILES) { x0 >>= o.st_shift; x1 >>= o.st_shift; y0 >>= o.st_shift; y1 >>= o.st_shift; pitch = o.nsx; }
+    const uint32_t w = x1 - x0;           // width - 1
+    if (w + 1 >= o.world) return true;    // `world` consecutive ids hit every residue
+    if (y1 - y0 >= 8) return true;        // tall and narrow: rare, keep
+    for (uint32_t y = y0; y <= y1; y++) {
+        const uint32_t first = (y * pitch + x0) % o.world;
+        const uint32_t d = o.rank >= first ? o.rank - first : o.rank + o.world - first;
+        if (d <= w) return true;
+    }
+    return false;
+}
+
 // counters[]: [1] entries, [2] segments (two-pass scan), [3] overflow flags, then CTR_NSHARDS statistics shards of one
 // 128-byte line each: {surviving triangles, (triangle, bin) pairs, segments}.  One line per shard: atomics that share
 // a line serialise in its L2 channel (64 shards packed into two lines cost k_geom 20 us on the headline scene).
 // CTR_OVERFLOW bits: 1 record capacity (impossible), 2 two-pass queue capacity, 4 direct-mode per-bin queue full
 enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_SHARD_BASE = 32, CTR_SHARD_STRIDE = 32, CTR_NSHARDS = 128,
-       CTR_REC = 0, CTR_ENT = 1, CTR_SEG = 2, CTR_NUM = CTR_SHARD_BASE + CTR_NSHARDS * CTR_SHARD_STRIDE };
+       CTR_REC = 0, CTR_ENT = 1, CTR_SEG = 2, CTR_CULL = 3 /* geometry chunks culled against the ownership map */,
+       CTR_NUM = CTR_SHARD_BASE + CTR_NSHARDS * CTR_SHARD_STRIDE };
 #define MTR_CTR(kind, k) (CTR_SHARD_BASE + ((k) & (CTR_NSHARDS - 1)) * CTR_SHARD_STRIDE + (kind))
 
 struct FrameBuffers {
@@ -99,7 +157,7 @@ struct FrameBuffers {
     uint32_t* counters;             // CTR_*
     uint32_t rec_cap, entry_cap, seg_cap;
     uint32_t W, H, nbx, nby;
-    uint32_t shard_rank, shard_world;
+    Ownership own;
     // direct mode: single-pass binning into bounded per-bin queues (bin b owns entries[b*qcap ..) and
     // segs[b*scap ..), filled through bin_fill); overflow raises CTR_OVERFLOW bit 2 and the host re-runs the frame
     // with the exact two-pass (count, scan, fill) queues
@@ -136,8 +194,11 @@ struct GeomParams {
     const uint16_t* ibuf;
     const DPrim* prims;
     const DChunk* chunks;
+    const BoneBox* boxes;     // chunk bounds (DChunk::b_first indexes it), nullptr: no culling data
     uint32_t nchunks;
-    uint32_t ninst;
+    uint32_t ninst;           // instances of the draw
+    const uint32_t* inst_list;   // sharded batch draws: the instances that may touch this rank's bins (k_cull_instances),
+    const uint32_t* inst_count;  // and how many; nullptr: every instance 0 .. ninst-1
     const float* model_mats;  // ninst*16 or nullptr
     const float* palettes;    // per instance npal*16 floats (stride pal_stride floats) or nullptr
     uint32_t npal, pal_stride;
@@ -178,5 +239,23 @@ void mtr_launch_alpha_min(const uint8_t* rgba, size_t npixels, uint32_t* out_min
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s);
 void mtr_launch_bc1_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
 void mtr_launch_bc7_decode(const uint8_t* blocks, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t s);
-void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, hipStream_t s);
-void mtr_launch_unpack_shards(const uint8_t* gathered, uint8_t* color, uint32_t W, uint32_t H, uint32_t world, hipStream_t s);
+// own_list / own_count: the packing rank's bins; stride_bins: bins per rank in the gathered buffer (the largest share);
+// src_of_bin[b] = rank * stride_bins + k for the k-th bin of its owner
+void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t W, uint32_t H, const uint32_t* own_list, uint32_t own_count,
+                           uint32_t stride_bins, hipStream_t s);
+void mtr_launch_unpack_shards(const uint8_t* gathered, uint8_t* color, uint32_t W, uint32_t H, const uint32_t* src_of_bin, hipStream_t s);
+// instance culling of a sharded batch draw: the instances whose bounds may touch a bin of the rank -> list / count
+struct CullParams {
+    const BoneBox* boxes;      // per-joint boxes of the whole model, boxes[0] = the box of every vertex
+    uint32_t nboxes;
+    uint32_t ninst;
+    const float* model_mats;
+    const float* palettes;
+    uint32_t npal, pal_stride;
+    float vp[16];
+    uint32_t W, H, nbx, nby;
+    Ownership own;
+    uint32_t* list;
+    uint32_t* count;
+};
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t s);

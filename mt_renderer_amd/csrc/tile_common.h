@@ -119,15 +119,15 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     return v + (row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2);
 }
 
-// XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous bin range.
+// XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous run of this rank's bins
+// (own_list is row-major for interleaved / band ownership and super-tile-major for super-tiles).
 // Returns false when this block has no bin.
 __device__ __forceinline__ bool block_to_bin(const FrameBuffers& fb, uint32_t& bin) {
-    const uint32_t nbins = fb.nbx * fb.nby;
-    const uint32_t world = fb.shard_world ? fb.shard_world : 1u;
     const uint32_t per = (gridDim.x + 7) / 8;
     const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    bin = slot * world + fb.shard_rank;
-    return slot < (nbins + world - 1 - fb.shard_rank) / world && bin < nbins;
+    if (slot >= fb.own.own_count) return false;
+    bin = fb.own.own_list ? fb.own.own_list[slot] : slot;
+    return bin < fb.nbx * fb.nby;
 }
 
 }  // namespace mtr

@@ -19,8 +19,9 @@ void mtr_launch_vertex_stage(const GeomParams&, uint32_t, float*, float*, hipStr
 void mtr_launch_bc1_decode(const uint8_t*, uint8_t*, uint32_t, uint32_t, hipStream_t) {}
 void mtr_launch_bc7_decode(const uint8_t*, uint8_t*, uint32_t, uint32_t, hipStream_t) {}
 // the copies the real kernels make, so that the send / gathered / destination buffers are really written by this thread
-void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t) { dst[0] = color[0]; }
-void mtr_launch_unpack_shards(const uint8_t* g, uint8_t* dst, uint32_t, uint32_t, uint32_t, hipStream_t) { dst[0] = g[0]; }
+void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t, uint32_t, const uint32_t* own_list, uint32_t n, uint32_t, hipStream_t) { dst[0] = color[0] + (n ? (uint8_t)own_list[0] : 0); }
+void mtr_launch_unpack_shards(const uint8_t* g, uint8_t* dst, uint32_t, uint32_t, const uint32_t* src_of_bin, hipStream_t) { dst[0] = g[0] + (uint8_t)src_of_bin[0]; }
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) p.list[(*p.count)++] = i; }
 
 static std::atomic<long> g_calls{0};
 static int fake_allgather(const void* send, void* recv, size_t count, int, void*, void*) {
@@ -47,7 +48,8 @@ int main(int argc, char** argv) {
     mtr_model* model = nullptr;
     REQ(mtr_model_create(dev, verts, sizeof verts, idx, 3, &pr, 1, &l, nullptr, nullptr, 0, nullptr, &model));
     const uint32_t W = 64, H = 48, world = 2;
-    const size_t nbytes = mtr_shard_bytes(W, H, world);
+    const size_t nbytes = std::max({mtr_shard_bytes(W, H, world), mtr_shard_bytes_map(W, H, world, MTR_OWN_BANDS, 0, nullptr),
+                                    mtr_shard_bytes_map(W, H, world, MTR_OWN_SUPERTILES, 1, nullptr)});
     std::vector<uint8_t> send(nbytes), gathered(nbytes * world), final_((size_t)W * H * 4);
     int fake_stream = 0;
     REQ(mtr_device_exchange_start(dev, fake_allgather, nullptr, 1, send.data(), nbytes, gathered.data(), final_.data(), world, &fake_stream));
@@ -60,7 +62,8 @@ int main(int argc, char** argv) {
     for (long i = 0; i < frames; i++) {
         mtr_frame* f = nullptr;
         REQ(mtr_frame_begin(dev, W, H, clear, 1.0f, &f));
-        REQ(mtr_frame_set_shard(f, (uint32_t)(i & 1), world));
+        if (i % 3 == 0) REQ(mtr_frame_set_shard(f, (uint32_t)(i & 1), world));
+        else REQ(mtr_frame_set_shard_map(f, (uint32_t)(i & 1), world, i % 3 == 1 ? MTR_OWN_BANDS : MTR_OWN_SUPERTILES, 1, nullptr));
         if (i % 5 == 2) {
             // a frame that OWNS a temporary batch: the exchange thread destroys it (mtr_batch_destroy: garbage list,
             // frame index) while this thread keeps submitting

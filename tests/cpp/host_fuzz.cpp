@@ -25,8 +25,9 @@ void mtr_launch_bc1_decode(const uint8_t* b, uint8_t* rgba, uint32_t w, uint32_t
 void mtr_launch_bc7_decode(const uint8_t* b, uint8_t* rgba, uint32_t w, uint32_t h, hipStream_t) {
     memset(rgba, b[(size_t)((w + 3) / 4) * ((h + 3) / 4) * 16 - 1], (size_t)w * h * 4);
 }
-void mtr_launch_pack_shard(const uint8_t*, uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t) {}
-void mtr_launch_unpack_shards(const uint8_t*, uint8_t*, uint32_t, uint32_t, uint32_t, hipStream_t) {}
+void mtr_launch_pack_shard(const uint8_t*, uint8_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t, hipStream_t) {}
+void mtr_launch_unpack_shards(const uint8_t*, uint8_t*, uint32_t, uint32_t, const uint32_t*, hipStream_t) {}
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) p.list[(*p.count)++] = i; }
 
 static uint64_t rs = 0x243F6A8885A308D3ull;
 static uint64_t rnd() {
@@ -133,6 +134,12 @@ int main(int argc, char** argv) {
             mtr_frame* fr = nullptr;
             if (mtr_frame_begin(dev, W, H, clear, 1.0f, &fr) == MTR_OK) {
                 if (rnd() % 3 == 0) mtr_frame_set_shard(fr, weird() % 9, weird() % 9);
+                if (rnd() % 3 == 0) {  // ownership maps, band tables that are mostly malformed
+                    uint32_t bands[10];
+                    for (auto& b : bands) b = weird() % 40;
+                    if (rnd() % 2) bands[0] = 0;
+                    mtr_frame_set_shard_map(fr, weird() % 9, weird() % 9, weird() % 4, weird() % 9, rnd() % 2 ? bands : nullptr);
+                }
                 mtr_frame_draw_model(fr, model, M);
                 const uint32_t ninst = pick(0, 5);
                 std::vector<float> mm((size_t)(ninst ? ninst : 1) * 16, 1.0f), pp((size_t)(ninst ? ninst : 1) * 2 * 16, 0.25f);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libmtr.so does not export {n}"
     assert sorted(api.EXPORTED_SYMBOLS) == names
-    assert api.lib.mtr_abi_version() == 1
+    assert api.lib.mtr_abi_version() == 2
 
 
 def test_header_is_plain_c_and_struct_sizes():
@@ -36,7 +36,7 @@ def test_header_is_plain_c_and_struct_sizes():
 _Static_assert(sizeof(mtr_primitive) == 0x38, "PrimitiveInfo is 0x38 bytes (src/rmodel.rs:489)");
 _Static_assert(sizeof(mtr_element) == 8, "mtr_element");
 _Static_assert(sizeof(mtr_layout) == 4 + 8 * 8, "mtr_layout");
-_Static_assert(sizeof(mtr_frame_stats) == 56, "mtr_frame_stats");
+_Static_assert(sizeof(mtr_frame_stats) == 80, "mtr_frame_stats");
 int main(void) { return 0; }
 '''
     with tempfile.TemporaryDirectory() as td:
