@@ -359,6 +359,58 @@ class Batch:
             self._h = None
 
 
+class FrameLoop:
+    """A render loop body with every argument converted once: begin -> [set_shard] -> draw model / batch -> submit
+    [-> exchange] -> destroy, as five or six bare C calls per frame.  The classes above convert numpy arrays and build
+    ctypes objects on every call (about 20 us of interpreter time per frame, more than a sharded rank's GPU share of a
+    small frame); a native host of the C ABI pays about 10 us per frame (tools/probe/host_cost.cpp).  Same calls, same
+    order, same error checks -- only the argument marshalling is hoisted out of the loop."""
+
+    def __init__(self, dev: Device, width: int, height: int, *, model: Optional[Model] = None, batch: Optional[Batch] = None,
+                 view_proj: np.ndarray, clear_rgba=(1.0, 1.0, 1.0, 1.0), clear_depth: float = 1.0, shard=None, exchange: bool = False):
+        assert (model is None) != (batch is None)
+        self.dev = dev
+        self._clear = _f32(clear_rgba, 4)
+        self._vp = _f32(view_proj, 16)
+        self._keep = (model, batch)
+        self._begin_args = (dev._h, C.c_uint32(width), C.c_uint32(height), _p(self._clear), C.c_float(clear_depth))
+        self._draw = lib.mtr_frame_draw_model if model is not None else lib.mtr_frame_draw_batch
+        self._obj = (model or batch)._h
+        self._vp_p = _p(self._vp)
+        self._shard = None
+        if shard is not None:
+            sh = tuple(shard)
+            rank, world, own_map, param, bands = sh + (OWN_INTERLEAVED, 0, None)[len(sh) - 2:]
+            self._bands = None if bands is None else np.ascontiguousarray(bands, dtype=np.uint32)
+            self._shard = (C.c_uint32(rank), C.c_uint32(world), C.c_uint32(own_map), C.c_uint32(param), _p(self._bands))
+        self._exchange = exchange
+        self._h = C.c_void_p()
+        self._href = C.byref(self._h)
+
+    def run(self, n: int = 1):
+        """n frames: submitted, not waited for (dev.synchronize() / exchange_drain() afterwards reports any error)"""
+        begin, draw, submit, destroy, shard_fn = lib.mtr_frame_begin, self._draw, lib.mtr_frame_submit, lib.mtr_frame_destroy, lib.mtr_frame_set_shard_map
+        xchg = lib.mtr_frame_submit_exchange
+        h, href, ba, obj, vp, sh, check = self._h, self._href, self._begin_args, self._obj, self._vp_p, self._shard, self.dev.check
+        for _ in range(n):
+            rc = begin(*ba, href)
+            if rc:
+                check(rc)
+            if sh is not None:
+                rc = shard_fn(h, *sh)
+            rc = rc or draw(h, obj, vp)
+            if not rc:
+                if self._exchange:
+                    rc = xchg(h)
+                    if not rc:
+                        continue  # the exchange thread owns the frame now
+                else:
+                    rc = submit(h)
+            destroy(h)
+            if rc:
+                check(rc)
+
+
 class Frame:
     """One render pass: clear colour / depth as in src/bin/modelviewer.rs:190-210 (white, 1.0)."""
 

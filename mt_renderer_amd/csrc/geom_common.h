@@ -249,6 +249,50 @@ __device__ __forceinline__ ClipBox box_clip_interval(const BoneBox& b, const flo
     return r;
 }
 
+// the composite of one joint for the chunk tests: rows x, y, w of M * [P; 0 0 0 1] and of |M| * |P|
+__device__ __forceinline__ CompMat make_comp(const float* Pm, const float (&M)[16]) {
+    CompMat cm;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int i = t == 2 ? 3 : t;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float C, A;
+            if (Pm) {
+                C = M[0 + i] * Pm[c * 4 + 0] + M[4 + i] * Pm[c * 4 + 1] + M[8 + i] * Pm[c * 4 + 2];
+                A = fabsf(M[0 + i]) * fabsf(Pm[c * 4 + 0]) + fabsf(M[4 + i]) * fabsf(Pm[c * 4 + 1]) + fabsf(M[8 + i]) * fabsf(Pm[c * 4 + 2]);
+                if (c == 3) { C += M[12 + i]; A += fabsf(M[12 + i]); }
+            } else {
+                C = M[c * 4 + i];
+                A = fabsf(C);
+            }
+            cm.C[c * 3 + t] = C;
+            cm.A[c * 3 + t] = A;
+        }
+    }
+    return cm;
+}
+
+// the same interval as box_clip_interval from a prepared composite: 11 multiply-adds per clip coordinate
+__device__ __forceinline__ ClipBox box_comp_interval(const BoneBox& b, const CompMat& cm) {
+    const float cen[3] = {b.cx, b.cy, b.cz}, ext[3] = {b.ex, b.ey, b.ez};
+    ClipBox r;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        float v = cm.C[9 + t], rad = 0.0f, mag = cm.A[9 + t];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            v += cm.C[c * 3 + t] * cen[c];
+            rad += fabsf(cm.C[c * 3 + t]) * ext[c];
+            mag += cm.A[c * 3 + t] * (fabsf(cen[c]) + ext[c]);
+        }
+        const float m = mag * 1.52587890625e-05f;  // 2^-16
+        r.lo[t] = v - rad - m;
+        r.hi[t] = v + rad + m;
+    }
+    return r;
+}
+
 __device__ __forceinline__ bool clipbox_finite(const ClipBox& r) {
     bool ok = true;
 #pragma unroll
@@ -287,16 +331,17 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
     return v;
 }
-// the same over the first 16 lanes only (DPP rotations inside row 0, then lane 0 broadcast): a chunk has <= 16 boxes
-__device__ __forceinline__ float row0_min_f32(float v) {
+// the same inside each row of 16 lanes (DPP rotations; min / max are idempotent, so every lane of a row ends up with
+// the row's result): one wave bounds four chunks at once, a chunk has <= 16 boxes
+__device__ __forceinline__ float row_min_f32(float v) {
 #define MTR_ROR(x, c) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), c, 0xf, 0xf, false))
     v = fminf(v, MTR_ROR(v, 0x128)); v = fminf(v, MTR_ROR(v, 0x124)); v = fminf(v, MTR_ROR(v, 0x122)); v = fminf(v, MTR_ROR(v, 0x121));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    return v;
 }
-__device__ __forceinline__ float row0_max_f32(float v) {
+__device__ __forceinline__ float row_max_f32(float v) {
     v = fmaxf(v, MTR_ROR(v, 0x128)); v = fmaxf(v, MTR_ROR(v, 0x124)); v = fmaxf(v, MTR_ROR(v, 0x122)); v = fmaxf(v, MTR_ROR(v, 0x121));
 #undef MTR_ROR
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------

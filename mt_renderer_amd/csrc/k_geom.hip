@@ -13,6 +13,7 @@
 #include "geom_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace mtr {
 
@@ -122,31 +123,6 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
         for (uint32_t i = threadIdx.x; i < P.npal * 4; i += blockDim.x) reinterpret_cast<float4*>(s_pal)[i] = src[i];
     }
     __syncthreads();
-}
-
-// Conservative culling of one chunk against the rank's bins (geom_common.h): lane = one of the chunk's boxes.
-__device__ __forceinline__ bool chunk_may_touch_rank(const GeomParams& P, uint32_t inst, const DChunk& ch, bool skinned,
-                                                     const float (&M)[16], uint32_t lane) {
-    if (!P.boxes || ch.b_count == 0) return true;
-    if (skinned && (ch.b_flags & 1u)) return true;
-    const uint32_t first = skinned ? ch.b_first + 1u : ch.b_first, n = skinned ? ch.b_count - 1u : 1u;
-    if (n == 0 || n > MTR_CHUNK_MAX_BOXES) return true;
-    ClipBox cb;
-#pragma unroll
-    for (int t = 0; t < 3; t++) { cb.lo[t] = __builtin_inff(); cb.hi[t] = -__builtin_inff(); }
-    bool bad = false;
-    if (lane < n) {
-        const BoneBox bx = P.boxes[first + lane];
-        const float* Pm = nullptr;
-        if (skinned) Pm = P.palettes + (size_t)inst * P.pal_stride + (size_t)min(bx.joint, P.npal - 1u) * 16;
-        cb = box_clip_interval(bx, Pm, M);
-        bad = !clipbox_finite(cb);
-    }
-    if (__ballot(bad)) return true;
-    ClipBox u;
-#pragma unroll
-    for (int t = 0; t < 3; t++) { u.lo[t] = row0_min_f32(cb.lo[t]); u.hi[t] = row0_max_f32(cb.hi[t]); }
-    return clipbox_may_touch_rank(u, P.fb);
 }
 
 // MODE 0: count pass of the exact two-pass queues; 1: single-pass binning, ordered segments; 2: single-pass binning
@@ -317,11 +293,11 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 #define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
                     // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
 #endif
-// grid = (blocks of 4 chunks, instance slots), 256 threads: wave = one chunk of one instance.  A sharded frame first
-// tests the chunk's bounds against the rank's bins (a handful of lanes, ~150 instructions) and a workgroup whose four
-// chunks all miss leaves before the palette is even staged; a sharded batch draw walks the compacted instance list
-// k_cull_instances wrote, gridDim.y instances at a time.
-// CULL: the sharded variant (bounds test, instance list); the unsharded kernel carries none of it.
+// 256 threads, wave = one chunk (62 strip positions) of one instance.  Unsharded frames (CULL false): grid = (blocks
+// of 4 chunks, instances).  Sharded frames (CULL true): k_cull_chunks has bounded every chunk against the rank's bins
+// and written the survivors to a work list; the workgroups stride over it.  (Testing the bounds inside this kernel --
+// 80 registers, 6 workgroups per CU -- put the test's chain of dependent loads on every workgroup's critical path:
+// +11 us on the headline scene even when nothing was culled.)
 template <int MODE, bool CULL>
 __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
@@ -329,70 +305,69 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of
-    // chunks so neighbouring strips (which share a vertex row) hit the same L2.  Speed only.
-    const uint32_t nblk = gridDim.x;
-    const uint32_t per = (nblk + 7) / 8;
-    const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const uint32_t c = blk * 4 + wave;
-    if (blk >= nblk) return;  // whole workgroup
-    const bool has_chunk = c < P.nchunks;
-    DChunk ch = {};
-    DPrim pr = {};
-    if (has_chunk) { ch = P.chunks[c]; pr = P.prims[ch.prim]; }
-    const bool skinned = pr.skinnable && P.palettes && P.npal;
     if (!CULL) {  // one instance per blockIdx.y, nothing to test
+        // blocks b and b+8 share an XCD (observed round-robin dispatch): give each XCD a contiguous run of
+        // chunks so neighbouring strips (which share a vertex row) hit the same L2.  Speed only.
+        const uint32_t nblk = gridDim.x;
+        const uint32_t per = (nblk + 7) / 8;
+        const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        const uint32_t c = blk * 4 + wave;
+        if (blk >= nblk) return;  // whole workgroup
         stage_palette(P, blockIdx.y, s_pal);  // every thread of the workgroup copies its share
-        if (!has_chunk) return;
+        if (c >= P.nchunks) return;
+        const DChunk ch = P.chunks[c];
+        const DPrim pr = P.prims[ch.prim];
         float M[16];
         compose_matrix(P, blockIdx.y, M);
-        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, skinned, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
         return;
     }
-    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
-    bool first_pass = true;
-    for (uint32_t ii = blockIdx.y; ii < nlive; ii += gridDim.y) {
-        const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
-        float M[16];
-        compose_matrix(P, inst, M);
-        bool keep = has_chunk;
-        if (P.fb.own.cull) {
-            if (keep) keep = chunk_may_touch_rank(P, inst, ch, skinned, M, lane);
-            if (has_chunk && !keep && lane == 0) {
-                const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
-                if (MODE == 0) { ChunkInfo ci = {gid * MTR_CHUNK_SLOTS, 0u}; P.fb.chunk_info[gid] = ci; }
-                atomicAdd(&P.fb.counters[MTR_CTR(CTR_CULL, gid)], 1u);  // statistics only
-            }
-            // also the barrier that lets the palette of the previous pass be overwritten
-            if (!__syncthreads_or(keep ? 1 : 0)) continue;
-        } else if (!first_pass) {
-            __syncthreads();
-        }
-        first_pass = false;
-        stage_palette(P, inst, s_pal);
-        if (keep) geom_chunk<MODE>(P, inst, c, ch, pr, skinned, M, s_pal, s_hdr[wave], s_slot[wave], lane);
-    }
+    // sharded: workgroup g takes group g / nsub of sub-list g % nsub of the work k_cull_chunks wrote (four chunks of one
+    // instance); the launch covers every sub-list's capacity and the workgroups past a sub-list's end leave at once.
+    // (Striding over the lists inside the kernel made the register allocator spill into the hot path: 249 us instead
+    // of 186 us for k_geom on C5 at N = 8, dead workgroups included.)
+    const uint32_t sub = blockIdx.x % P.work_nsub, gi = blockIdx.x / P.work_nsub;
+    if (gi * 4u >= P.work_counts[sub * MTR_CULL_CTR_STRIDE]) return;
+    const uint2* grp = P.work_list + (size_t)sub * P.work_sub_cap + gi * 4u;
+    const uint2 e = grp[wave];
+    const uint32_t inst = grp[0].y;  // the first entry of a group is never padding
+    stage_palette(P, inst, s_pal);
+    if (e.x == 0xFFFFFFFFu) return;
+    const DChunk ch = P.chunks[e.x];
+    const DPrim pr = P.prims[ch.prim];
+    float M[16];
+    compose_matrix(P, inst, M);
+    geom_chunk<MODE>(P, inst, e.x, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
 }
 
-// Instance culling of a sharded batch draw: one wave per instance, lane = per-joint box of the whole model.  The
-// instances whose bounds may reach a bin of this rank are appended to `list` (in no particular order: k_geom takes the
-// instance number from the list, so submission-order keys do not change).
-__global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
-    const uint32_t inst = blockIdx.x, lane = threadIdx.x;
-    if (inst >= P.ninst) return;
-    float M[16];
-    {
-        const float* B = P.model_mats + (size_t)inst * 16;  // M = VP * Model, the chain of compose_matrix
+__device__ __forceinline__ void compose_vp_model(const float (&vp)[16], const float* model_mats, uint32_t inst, float (&M)[16]) {
+    if (model_mats) {
+        const float* B = model_mats + (size_t)inst * 16;  // M = VP * Model, the chain of compose_matrix
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float a = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 4; k++) a = fmaf(P.vp[k * 4 + i], B[c * 4 + k], a);
+                for (int k = 0; k < 4; k++) a = fmaf(vp[k * 4 + i], B[c * 4 + k], a);
                 M[c * 4 + i] = a;
             }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) M[i] = vp[i];
     }
+}
+
+// Instance culling of a sharded batch draw, one wave per instance, lane = per-joint box of the whole model: the
+// instances that may reach a bin of this rank are appended to `list` (in no particular order: k_geom takes the instance
+// number from the work list, so submission-order keys do not change).
+__global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
+    const uint32_t inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= P.ninst) return;
+    float M[16];
+    compose_vp_model(P.vp, P.model_mats, inst, M);
+    const bool have_pal = P.palettes && P.npal;
+    const float* pal = have_pal ? P.palettes + (size_t)inst * P.pal_stride : nullptr;
     ClipBox cb;
 #pragma unroll
     for (int t = 0; t < 3; t++) { cb.lo[t] = __builtin_inff(); cb.hi[t] = -__builtin_inff(); }
@@ -400,7 +375,7 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
     for (uint32_t i = lane; i < P.nboxes; i += 64) {
         const BoneBox bx = P.boxes[i];
         const float* Pm = nullptr;
-        if (bx.joint != MTR_BOX_UNSKINNED && P.palettes && P.npal) Pm = P.palettes + (size_t)inst * P.pal_stride + (size_t)min(bx.joint, P.npal - 1u) * 16;
+        if (bx.joint != MTR_BOX_UNSKINNED && have_pal) Pm = pal + (size_t)min(bx.joint, P.npal - 1u) * 16;
         const ClipBox one = box_clip_interval(bx, Pm, M);
         bad = bad || !clipbox_finite(one);
 #pragma unroll
@@ -415,7 +390,85 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
         fb.W = P.W; fb.H = P.H; fb.nbx = P.nbx; fb.nby = P.nby; fb.own = P.own;
         keep = clipbox_may_touch_rank(u, fb);
     }
-    if (keep && lane == 0) P.list[atomicAdd(P.count, 1u)] = inst;
+    if (!keep) return;
+    if (lane == 0) P.list[atomicAdd(P.count, 1u)] = inst;
+    if (P.comp) {  // what the chunk tests of this instance read (k_cull_chunks)
+        CompMat* out = P.comp + (size_t)inst * P.ncomp;
+        for (uint32_t j = lane; j < P.ncomp; j += 64) out[j] = make_comp((have_pal && j + 1 < P.ncomp) ? pal + (size_t)j * 16 : nullptr, M);
+    }
+}
+
+// Chunk culling of a sharded draw.  256 threads = 16 rows of 16 lanes: row = one chunk, lane = one of its boxes; the
+// per-joint composites of the instance are built once per workgroup in LDS.  The chunks that may reach a bin of the
+// rank are appended to the work list in groups of four of the same instance (padded with 0xFFFFFFFF), which is what a
+// k_geom workgroup -- one palette in LDS, four waves -- consumes.  A light kernel (no records, no binning state) at
+// full occupancy: the test's chain of dependent loads is not paid inside k_geom's 80-register workgroups.
+template <bool LDS_COMP>  // true: the workgroup builds its instance's composites in LDS (a single model); false: they come from k_cull_instances
+__global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCullParams P) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    CompMat* s_comp = reinterpret_cast<CompMat*>(s_raw);
+    __shared__ uint32_t s_wmask[4];
+    __shared__ uint32_t s_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, sub = lane & 15u;
+    const uint32_t c = blockIdx.x * 16u + wave * 4u + row;
+    const bool has = c < P.nchunks;
+    DChunk ch = {};
+    if (has) ch = P.chunks[c];
+    const bool have_pal = P.palettes && P.npal;
+    const uint32_t ncomp = have_pal ? P.npal + 1u : 1u;
+    const bool skinned = (ch.b_flags & 2u) && have_pal;
+    // chunks that cannot be bounded are kept
+    const bool unbounded = has && (ch.b_count == 0 || (skinned && (ch.b_flags & 1u)) || (skinned && ch.b_count < 2) || ch.b_count > MTR_CHUNK_MAX_BOXES + 1u);
+    const uint32_t first = skinned ? ch.b_first + 1u : ch.b_first, n = has ? (skinned ? ch.b_count - 1u : 1u) : 0u;
+    BoneBox bx = {};
+    const bool tests = has && !unbounded && sub < n;
+    if (tests) bx = P.boxes[first + sub];
+    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    for (uint32_t ii = blockIdx.y; ii < nlive; ii += gridDim.y) {
+        const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
+        __syncthreads();  // the composites and masks of the previous instance are no longer read
+        if (LDS_COMP) {
+            float M[16];
+            compose_vp_model(P.vp, P.model_mats, inst, M);
+            const float* pal = have_pal ? P.palettes + (size_t)inst * P.pal_stride : nullptr;
+            for (uint32_t j = threadIdx.x; j < ncomp; j += 256) s_comp[j] = make_comp((have_pal && j + 1 < ncomp) ? pal + (size_t)j * 16 : nullptr, M);
+        }
+        __syncthreads();
+        ClipBox cb;
+#pragma unroll
+        for (int t = 0; t < 3; t++) { cb.lo[t] = __builtin_inff(); cb.hi[t] = -__builtin_inff(); }
+        bool bad = false;
+        if (tests) {
+            const uint32_t j = skinned ? min(bx.joint, P.npal - 1u) : ncomp - 1u;  // the last composite is M itself
+            cb = box_comp_interval(bx, LDS_COMP ? s_comp[j] : P.comp[(size_t)inst * ncomp + j]);
+            bad = !clipbox_finite(cb);
+        }
+        const uint64_t badm = __ballot(bad);
+        const bool row_bad = ((badm >> (row * 16u)) & 0xFFFFull) != 0;
+        ClipBox u;
+#pragma unroll
+        for (int t = 0; t < 3; t++) { u.lo[t] = row_min_f32(cb.lo[t]); u.hi[t] = row_max_f32(cb.hi[t]); }
+        const bool keep = has && (unbounded || row_bad || P.keep_all || clipbox_may_touch_rank(u, P.fb));
+        const uint64_t km = __ballot(keep);
+        if (lane == 0)
+            s_wmask[wave] = (uint32_t)(km & 1ull) | (uint32_t)((km >> 15) & 2ull) | (uint32_t)((km >> 30) & 4ull) | (uint32_t)((km >> 45) & 8ull);
+        __syncthreads();
+        const uint32_t m16 = s_wmask[0] | (s_wmask[1] << 4) | (s_wmask[2] << 8) | (s_wmask[3] << 12);
+        const uint32_t k = (uint32_t)__popc(m16), k4 = (k + 3u) & ~3u;
+        const uint32_t sl = (blockIdx.x + ii) % P.work_nsub;
+        if (threadIdx.x == 0) {
+            s_base = k ? sl * P.work_sub_cap + atomicAdd(&P.work_counts[sl * MTR_CULL_CTR_STRIDE], k4) : 0u;
+            const uint32_t nhave = blockIdx.x * 16u < P.nchunks ? min(16u, P.nchunks - blockIdx.x * 16u) : 0u;
+            if (nhave > k) atomicAdd(&P.fb.counters[MTR_CTR(CTR_CULL, blockIdx.x + inst)], nhave - k);  // statistics only
+        }
+        __syncthreads();
+        if (threadIdx.x < 16u) {
+            if ((m16 >> threadIdx.x) & 1u)
+                P.work_list[s_base + (uint32_t)__popc(m16 & ((1u << threadIdx.x) - 1u))] = make_uint2(blockIdx.x * 16u + threadIdx.x, inst);
+        } else if (threadIdx.x < 16u + (k4 - k)) {
+            P.work_list[s_base + k + (threadIdx.x - 16u)] = make_uint2(0xFFFFFFFFu, inst);
+        }
+    }
 }
 
 // vertex stage alone (unit-parity hook: mtr_model_vertex_stage)
@@ -439,30 +492,37 @@ __global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t pri
 
 void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     if (p.nchunks == 0 || p.ninst == 0) return;
-    uint32_t nblk = (p.nchunks + 3) / 4;
-    nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
-    // a culled instance list is usually a fraction of the draw: launch instance slots for twice the rank's fair share
-    // (the kernel strides over the list, whatever its length turns out to be)
-    uint32_t ny = p.ninst;
-    if (p.inst_count && p.fb.own.world > 1) ny = std::max<uint32_t>(1u, std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world));
-    ny = std::min<uint32_t>(ny, 65535u);
-    dim3 grid(nblk, ny);
     size_t lds = (size_t)p.npal * 64;
-    const bool cull = p.fb.own.cull || p.inst_list;
-    if (cull) {
+    if (p.work_list) {
+        // sharded: one workgroup per group of every sub-list's capacity (the lengths are only known on the device)
+        dim3 grid(p.work_nsub * (p.work_sub_cap / 4));
         if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
         else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);
-    } else {
-        if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, false>), grid, dim3(256), lds, s, p);
-        else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, false>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((mtr::k_geom<0, false>), grid, dim3(256), lds, s, p);
+        return;
     }
+    uint32_t nblk = (p.nchunks + 3) / 4;
+    nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
+    dim3 grid(nblk, p.ninst);
+    if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, false>), grid, dim3(256), lds, s, p);
+    else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, false>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((mtr::k_geom<0, false>), grid, dim3(256), lds, s, p);
 }
 
 void mtr_launch_cull_instances(const CullParams& p, hipStream_t s) {
     if (p.ninst == 0) return;
     hipLaunchKernelGGL(mtr::k_cull_instances, dim3(p.ninst), dim3(64), 0, s, p);
+}
+
+void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t s) {
+    if (p.nchunks == 0 || p.ninst == 0) return;
+    // instance slots: the kernel strides over the (possibly compacted) instance list; twice the rank's fair share
+    uint32_t ny = p.ninst;
+    if (p.inst_count && p.fb.own.world > 1) ny = std::max<uint32_t>(1u, std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world));
+    ny = std::min<uint32_t>(ny, 65535u);
+    const uint32_t ncomp = (p.palettes && p.npal) ? p.npal + 1u : 1u;
+    if (p.comp) hipLaunchKernelGGL(mtr::k_cull_chunks<false>, dim3((p.nchunks + 15) / 16, ny), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(mtr::k_cull_chunks<true>, dim3((p.nchunks + 15) / 16, ny), dim3(256), (size_t)ncomp * sizeof(CompMat), s, p);
 }
 
 void mtr_launch_vertex_stage(const GeomParams& p, uint32_t prim, float* out_clip, float* out_uv, hipStream_t s) {

@@ -137,14 +137,15 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
 
 // waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
 // the keys are order-independent, so the waves only meet at the two barriers around the raster loop.
-#ifndef VIS_WAVES
-#define VIS_WAVES 2  // measured on the headline scene (tools/sweep_vis_waves.sh): 1: 104 us, 2: 73 us, 4: 83 us, 8: 129 us
-#endif
+// measured on the unsharded headline scene (tools/sweep_vis_waves.sh): 1 wave per bin: 104 us, 2: 73 us, 4: 83 us, 8: 129 us
 #ifndef VIS_OCC
 #define VIS_OCC 6    // waves per SIMD the register allocator must leave room for (no spills at 6)
 #endif
 
-template <bool TEX>
+// VIS_WAVES: 2 for unsharded frames (see above); a sharded rank has few bins and the frame then takes as long as its
+// heaviest bin (629 triangles = 183 batches of 64 pairs on the headline scene: 23 us with two waves), so the host
+// gives such frames 4 or 8 waves per bin (mtr_launch_tile_vis).
+template <bool TEX, int VIS_WAVES>
 __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams P) {
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
     __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
@@ -366,6 +367,12 @@ void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
     const uint32_t mine = p.fb.own.own_count;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
-    if (textured) hipLaunchKernelGGL(mtr::k_tile_vis<true>, dim3(grid), dim3(64 * VIS_WAVES), 0, s, p);
-    else hipLaunchKernelGGL(mtr::k_tile_vis<false>, dim3(grid), dim3(64 * VIS_WAVES), 0, s, p);
+    int waves = 2;
+    if (p.vis_waves) waves = (int)p.vis_waves;
+    else if (mine <= 1536) waves = 8;   // 256 CUs: every bin is resident at once, the heaviest bin bounds the frame
+    else if (mine <= 4096) waves = 4;
+#define MTR_LAUNCH_VIS(T, W) hipLaunchKernelGGL((mtr::k_tile_vis<T, W>), dim3(grid), dim3(64 * W), 0, s, p)
+    if (textured) { if (waves >= 8) MTR_LAUNCH_VIS(true, 8); else if (waves >= 4) MTR_LAUNCH_VIS(true, 4); else MTR_LAUNCH_VIS(true, 2); }
+    else { if (waves >= 8) MTR_LAUNCH_VIS(false, 8); else if (waves >= 4) MTR_LAUNCH_VIS(false, 4); else MTR_LAUNCH_VIS(false, 2); }
+#undef MTR_LAUNCH_VIS
 }

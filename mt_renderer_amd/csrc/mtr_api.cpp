@@ -62,6 +62,12 @@ struct Slot {
     uint32_t* inst_list = nullptr;   // sharded batch draws: compacted instance lists, draw after draw
     uint32_t* inst_count = nullptr;  // one counter per draw
     uint32_t inst_cap = 0, draw_cap = 0;
+    uint2* work_list = nullptr;      // sharded draws: the chunks that survive culling (k_cull_chunks -> k_geom), draw after draw
+    uint32_t work_cap = 0;
+    bool cull_counts_dirty = true;   // inst_count (MTR_CULL_CTR_WORDS per draw: instance-list length, work sub-list lengths) needs a fill
+    uint32_t ctr_clean_draws = 0;    // draws whose counters the last tile kernel cleared
+    CompMat* comp = nullptr;         // sharded batch draws: per (instance, joint) composites, k_cull_instances -> k_cull_chunks
+    uint32_t comp_cap = 0;
     uint32_t bin_cap = 0;
     uint32_t* entries = nullptr;  // submission order of every (triangle, bin) pair
     Seg* segs = nullptr;
@@ -133,6 +139,7 @@ struct mtr_device {
     std::vector<std::pair<uint64_t, uint32_t>> fb_allocated;  // (w << 32 | h) -> colour / depth sets ever allocated
     std::vector<std::unique_ptr<OwnTable>> own_tables;  // grow-only cache (submit_mu)
     bool cull_enabled = true;   // sharded frames cull chunks / instances against the rank's bins
+    uint32_t vis_waves = 0;     // MTR_VIS_WAVES: waves per bin of the visibility kernel, 0 = by the number of bins
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
     struct Exchange* xchg = nullptr;  // exchange thread of a sharded device (mtr_device_exchange_start)
 };
@@ -660,7 +667,7 @@ void rebuild_chunks(mtr_model* m) {
             }
             c.ntris = nt;
             const size_t sc = m->prim_chunk_base[p] + start / MTR_CHUNK_NEW;
-            c.b_first = m->cb_first[sc]; c.b_count = m->cb_count[sc]; c.b_flags = m->cb_flags[sc]; c.pad = 0;
+            c.b_first = m->cb_first[sc]; c.b_count = m->cb_count[sc]; c.b_flags = m->cb_flags[sc] | (pr.skinnable ? 2u : 0u); c.pad = 0;
             m->ntris_visible += nt;
             m->chunks.push_back(c);
         }
@@ -703,6 +710,10 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
                                   hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&d->status_dev), d->status_host, 0));
     for (uint32_t i = 0; i < mtr_device::kMaxInflight; i++) { d->status_host[i] = 0x80000000u; d->status_checked[i] = true; }
+    if (const char* e = getenv("MTR_VIS_WAVES")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v == 2 || v == 4 || v == 8) d->vis_waves = (uint32_t)v;
+    }
     if (const char* e = getenv("MTR_MAX_INFLIGHT")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 1 && v <= (long)mtr_device::kMaxInflight) d->max_inflight = (uint32_t)v;
@@ -739,7 +750,7 @@ void mtr_device_destroy(mtr_device* d) {
     }
     for (Slot& sl : d->slots) {
         void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
-                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count};
+                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count, sl.work_list, sl.comp};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1447,7 +1458,10 @@ static int32_t run_frame(mtr_frame* f) {
         fb.own.st_shift = t.st_shift; fb.own.nsx = t.nsx;
         fb.own.own_count = t.offs[f->shard_rank + 1] - t.offs[f->shard_rank];
         fb.own.own_list = t.d_lists + t.offs[f->shard_rank];
-        fb.own.cull = d->cull_enabled ? 1u : 0u;
+        // interleaved bins: a chunk's rectangle holds a bin of every rank as soon as it is `world` bins wide, so there
+        // is next to nothing to cull (and the work list would only cost): culling is for bands and super-tiles
+        fb.own.cull = (d->cull_enabled && t.map != MTR_OWN_INTERLEAVED) ? 1u : 0u;
+        if (const char* e = getenv("MTR_CULL_DEBUG")) fb.own.cull = (uint32_t)strtol(e, nullptr, 10);  // timing ablations only
     }
     fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
     // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a
@@ -1473,29 +1487,58 @@ static int32_t run_frame(mtr_frame* f) {
         HIPCHK(d, hipMemsetAsync(sl.bin_fill, 0, (size_t)sl.bin_cap * sizeof(unsigned long long), sg));
         sl.bin_fill_dirty = false;
     }
-    // sharded batch draws: cull the instances against this rank's bins first (k_cull_instances -> compacted lists)
-    std::vector<uint32_t> inst_off(f->draws.size(), 0xFFFFFFFFu);
+    // sharded draws: k_cull_instances compacts the instance list of a batch draw to the instances that may reach this
+    // rank's bins, k_cull_chunks then bounds every chunk of the surviving instances and writes the work list of k_geom
+    const size_t ndraws = f->draws.size();
+    std::vector<uint32_t> inst_off(ndraws, 0xFFFFFFFFu), work_off(ndraws, 0u), comp_off(ndraws, 0u), nsub(ndraws, 1u), sub_cap(ndraws, 0u);
     if (fb.own.cull) {
-        uint64_t ninst_total = 0;
-        for (size_t di = 0; di < f->draws.size(); di++) {
+        uint64_t ninst_total = 0, work_total = 0, comp_total = 0;
+        for (size_t di = 0; di < ndraws; di++) {
             const Draw& dr = f->draws[di];
-            if (!dr.d_model_mats) continue;  // a single model: chunk culling only
             const mtr_model* m = dr.model;
             const bool sk = dr.d_palettes && dr.npal;
+            // a cull workgroup (16 chunks) of instance slot ii appends to sub-list (x + ii) % nsub: <= ceil(nx / nsub) of
+            // them per instance slot and sub-list, 16 entries each at most
+            const uint64_t nx = ((uint64_t)m->chunks.size() + 15) / 16;
+            nsub[di] = (uint32_t)std::min<uint64_t>(MTR_CULL_MAX_SUB, std::max<uint64_t>(nx, 1));
+            const uint64_t cap = (nx + nsub[di] - 1) / nsub[di] * 16 * dr.ninst;
+            if (cap > 0x7FFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
+            sub_cap[di] = (uint32_t)cap;
+            work_off[di] = (uint32_t)work_total;
+            work_total += cap * nsub[di];
+            if (!dr.d_model_mats) continue;  // a single model: chunk culling only
             if (sk ? (!m->inst_skinned_boundable || m->n_inst_skinned == 0) : (m->n_inst_unskinned == 0)) continue;
             inst_off[di] = (uint32_t)ninst_total;
             ninst_total += dr.ninst;
+            comp_off[di] = (uint32_t)comp_total;
+            comp_total += (uint64_t)dr.ninst * (sk ? dr.npal + 1u : 1u);
         }
-        if (ninst_total) {
-            if (ninst_total > sl.inst_cap || f->draws.size() > sl.draw_cap || !sl.inst_list) {
-                HIPCHK(d, hipStreamSynchronize(sl.stream));
-                if ((rc = dev_grow(d, &sl.inst_list, &sl.inst_cap, ninst_total))) return rc;
-                if ((rc = dev_grow(d, &sl.inst_count, &sl.draw_cap, std::max<size_t>(f->draws.size(), 16)))) return rc;
-            }
-            HIPCHK(d, hipMemsetAsync(sl.inst_count, 0, f->draws.size() * sizeof(uint32_t), sg));
-            // the exact two-pass fill walks every chunk's run descriptor: the chunks of culled instances write none
-            if (!fb.direct) HIPCHK(d, hipMemsetAsync(sl.chunk_info, 0, total_chunks * sizeof(ChunkInfo), sg));
+        if (work_total > 0xFFFFFFF0ull || comp_total > 0xFFFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded frame");
+        if (comp_total > sl.comp_cap || !sl.comp) {
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
+            if ((rc = dev_grow(d, &sl.comp, &sl.comp_cap, std::max<uint64_t>(comp_total, 64)))) return rc;
         }
+        if (work_total > sl.work_cap || !sl.work_list) {
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
+            if ((rc = dev_grow(d, &sl.work_list, &sl.work_cap, work_total))) return rc;
+        }
+        if (ninst_total > sl.inst_cap || !sl.inst_list) {
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
+            if ((rc = dev_grow(d, &sl.inst_list, &sl.inst_cap, std::max<uint64_t>(ninst_total, 64)))) return rc;
+        }
+        if (ndraws > sl.draw_cap || !sl.inst_count) {
+            HIPCHK(d, hipStreamSynchronize(sl.stream));
+            uint32_t words = sl.draw_cap * MTR_CULL_CTR_WORDS;
+            if ((rc = dev_grow(d, &sl.inst_count, &words, (size_t)MTR_CULL_CTR_WORDS * std::max<size_t>(ndraws, 4)))) return rc;
+            sl.draw_cap = words / MTR_CULL_CTR_WORDS;
+            sl.cull_counts_dirty = true;
+        }
+        // the counters start from zero: the tile kernel of the slot's previous frame cleared them (TileParams::zero_words)
+        if (sl.cull_counts_dirty || ndraws > sl.ctr_clean_draws)
+            HIPCHK(d, hipMemsetAsync(sl.inst_count, 0, (size_t)sl.draw_cap * MTR_CULL_CTR_WORDS * sizeof(uint32_t), sg));
+        sl.cull_counts_dirty = true;  // until a tile kernel that clears them has been queued (below)
+        // the exact two-pass fill walks every chunk's run descriptor: culled chunks write none
+        if (!fb.direct) HIPCHK(d, hipMemsetAsync(sl.chunk_info, 0, total_chunks * sizeof(ChunkInfo), sg));
     }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[0], sg));
     uint32_t chunk_base = 0;
@@ -1522,16 +1565,31 @@ static int32_t run_frame(mtr_frame* f) {
         gp.chunk_base = chunk_base; gp.mat_base = mat_base[di]; gp.mat_inst_stride = mat_stride[di];
         gp.fb = fb;
         gp.mats = sl.mats;
-        if (inst_off[di] != 0xFFFFFFFFu) {
-            CullParams cp{};
+        if (fb.own.cull) {
             const bool sk = dr.d_palettes && dr.npal;
-            cp.boxes = m->d_inst_boxes + (sk ? m->n_inst_unskinned : 0); cp.nboxes = sk ? m->n_inst_skinned : m->n_inst_unskinned;
-            cp.ninst = dr.ninst; cp.model_mats = dr.d_model_mats; cp.palettes = gp.palettes; cp.npal = gp.npal; cp.pal_stride = gp.pal_stride;
-            memcpy(cp.vp, dr.vp, sizeof cp.vp);
-            cp.W = f->w; cp.H = f->h; cp.nbx = nbx; cp.nby = nby; cp.own = fb.own;
-            cp.list = sl.inst_list + inst_off[di]; cp.count = sl.inst_count + di;
-            mtr_launch_cull_instances(cp, sg);
-            gp.inst_list = cp.list; gp.inst_count = cp.count;
+            uint32_t* inst_cnt = nullptr;
+            if (inst_off[di] != 0xFFFFFFFFu) {
+                CullParams cp{};
+                cp.boxes = m->d_inst_boxes + (sk ? m->n_inst_unskinned : 0); cp.nboxes = sk ? m->n_inst_skinned : m->n_inst_unskinned;
+                cp.ninst = dr.ninst; cp.model_mats = dr.d_model_mats; cp.palettes = gp.palettes; cp.npal = gp.npal; cp.pal_stride = gp.pal_stride;
+                memcpy(cp.vp, dr.vp, sizeof cp.vp);
+                cp.W = f->w; cp.H = f->h; cp.nbx = nbx; cp.nby = nby; cp.own = fb.own;
+                cp.list = sl.inst_list + inst_off[di]; cp.count = inst_cnt = sl.inst_count + di * MTR_CULL_CTR_WORDS;
+                cp.comp = sl.comp + comp_off[di]; cp.ncomp = sk ? dr.npal + 1u : 1u;
+                mtr_launch_cull_instances(cp, sg);
+            }
+            ChunkCullParams cc{};
+            cc.chunks = m->d_chunks; cc.boxes = m->d_boxes; cc.nchunks = gp.nchunks; cc.ninst = dr.ninst;
+            cc.inst_list = inst_cnt ? sl.inst_list + inst_off[di] : nullptr; cc.inst_count = inst_cnt;
+            cc.model_mats = dr.d_model_mats; cc.palettes = gp.palettes; cc.npal = gp.npal; cc.pal_stride = gp.pal_stride;
+            memcpy(cc.vp, dr.vp, sizeof cc.vp);
+            cc.fb = fb;
+            cc.comp = inst_cnt ? sl.comp + comp_off[di] : nullptr;
+            cc.work_list = sl.work_list + work_off[di]; cc.work_counts = sl.inst_count + di * MTR_CULL_CTR_WORDS + MTR_CULL_CTR_STRIDE;
+            cc.work_nsub = nsub[di]; cc.work_sub_cap = sub_cap[di];
+            cc.keep_all = fb.own.cull == 3u ? 1u : 0u;
+            mtr_launch_cull_chunks(cc, sg);
+            gp.work_list = cc.work_list; gp.work_counts = cc.work_counts; gp.work_nsub = cc.work_nsub; gp.work_sub_cap = cc.work_sub_cap;
         }
         mtr_launch_geom(gp, sg);
         chunk_base += gp.nchunks * dr.ninst;
@@ -1555,6 +1613,12 @@ static int32_t run_frame(mtr_frame* f) {
     tp.zero_next = f->fb.other();
     f->fb.next_zeroed = fb.own.own_count != 0;  // a rank without a bin launches no tile workgroup
     tp.host_status = d->status_dev + sidx;
+    tp.vis_waves = d->vis_waves;
+    if (fb.own.cull && fb.own.own_count) {  // this frame's tile kernel clears the slot's culling counters for the next one
+        tp.zero_words = sl.inst_count; tp.zero_nwords = (uint32_t)ndraws * MTR_CULL_CTR_WORDS;
+        sl.cull_counts_dirty = false;
+        sl.ctr_clean_draws = (uint32_t)ndraws;  // what a frame with more draws than this one finds beyond is stale
+    }
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
     if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
     if (!use_vis) mtr_launch_tile(tp, any_textured, st);

@@ -42,7 +42,7 @@ struct DChunk {
     uint32_t b_first;   // object-space bounds of the chunk's vertices: bounds[b_first] is the box of all of them (what an
     uint32_t b_count;   // unskinned draw transforms), bounds[b_first + 1 ..) one box per joint that carries weight; 0: none
     uint32_t b_flags;   // bit0: the skinned position is not a convex combination (weights do not sum to 255, or too many
-    uint32_t pad;       //       joints for the table): never culled when skinned
+    uint32_t pad;       //       joints for the table): never culled when skinned; bit1: the primitive can be skinned
 };
 
 // object-space box of the vertices one joint influences inside one chunk (or of a whole model: instance culling)
@@ -53,7 +53,18 @@ struct BoneBox {
     uint32_t pad;
 };
 #define MTR_BOX_UNSKINNED 0xFFFFFFFFu
-#define MTR_CHUNK_MAX_BOXES 16
+#define MTR_CULL_MAX_SUB 64      // sub-lists of a draw's work list
+#define MTR_CULL_CTR_STRIDE 32   // words between two sub-list counters
+#define MTR_CULL_CTR_WORDS (MTR_CULL_CTR_STRIDE * (MTR_CULL_MAX_SUB + 1))  // per draw: word 0 = instance-list length, then the sub-list counters
+#define MTR_CHUNK_MAX_BOXES 15  // + the whole-chunk box = one row of 16 lanes
+
+// What the chunk test needs of one joint, per frame and instance: the clip rows x, y, w of C = M * [P_j; 0 0 0 1] and of
+// |M| * |P_j| (column-major 4 x 3: element [c * 3 + t], t = x, y, w), written by k_cull_prepare.  Entry npal of an
+// instance is M itself (what unskinned geometry is transformed by).
+struct CompMat {
+    float C[12];
+    float A[12];
+};
 
 struct DMat {            // one per (draw, [instance,] primitive)
     uint32_t shader;     // MTR_SH_*
@@ -197,8 +208,13 @@ struct GeomParams {
     const BoneBox* boxes;     // chunk bounds (DChunk::b_first indexes it), nullptr: no culling data
     uint32_t nchunks;
     uint32_t ninst;           // instances of the draw
-    const uint32_t* inst_list;   // sharded batch draws: the instances that may touch this rank's bins (k_cull_instances),
-    const uint32_t* inst_count;  // and how many; nullptr: every instance 0 .. ninst-1
+    // sharded draws (k_geom<MODE, true>): the work k_cull_chunks wrote -- groups of four (chunk, instance) pairs of ONE
+    // instance, chunk 0xFFFFFFFF = padding -- in work_nsub sub-lists of work_sub_cap entries each, sub-list s filled up to
+    // work_counts[s * MTR_CULL_CTR_STRIDE] (one counter per 128-byte line: appends to one address serialise at ~10 ns
+    // each, which cost 312 us of a C5 frame at N = 2 with a single list).  Workgroup g takes group g / nsub of sub-list g % nsub.
+    const uint2* work_list;
+    const uint32_t* work_counts;
+    uint32_t work_nsub, work_sub_cap;
     const float* model_mats;  // ninst*16 or nullptr
     const float* palettes;    // per instance npal*16 floats (stride pal_stride floats) or nullptr
     uint32_t npal, pal_stride;
@@ -227,6 +243,10 @@ struct TileParams {
     // soon as it starts (the geometry / scan kernels that raise the flags have completed by then), so the host -- the
     // render thread, or the exchange thread before it packs -- learns about a dropped triangle without a read-back
     uint32_t* host_status;
+    uint32_t vis_waves;  // waves per bin of the visibility kernel (2, 4, 8), 0: the launcher's choice (tuning hook: MTR_VIS_WAVES)
+    // the slot's culling counters (instance-list and work-list lengths), zeroed here for the slot's next frame
+    uint32_t* zero_words;
+    uint32_t zero_nwords;
 };
 
 // launchers (defined in the .hip files, called from mtr_api.cpp)
@@ -257,5 +277,28 @@ struct CullParams {
     Ownership own;
     uint32_t* list;
     uint32_t* count;
+    CompMat* comp;             // out, for the surviving instances: their per-joint composites (ncomp each, indexed by instance)
+    uint32_t ncomp;            // npal + 1 (skinned) or 1
 };
 void mtr_launch_cull_instances(const CullParams& p, hipStream_t s);
+// chunk culling of a sharded draw: every chunk of every (surviving) instance is bounded against the rank's bins; the
+// chunks that may reach one are appended to the work list k_geom consumes
+struct ChunkCullParams {
+    const DChunk* chunks;
+    const BoneBox* boxes;
+    uint32_t nchunks, ninst;
+    const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instances 0 .. ninst-1
+    const uint32_t* inst_count;
+    const float* model_mats;
+    const float* palettes;
+    uint32_t npal, pal_stride;
+    float vp[16];
+    FrameBuffers fb;             // W, H, nbx, nby, own, counters
+    const CompMat* comp;         // per-joint composites of every surviving instance (k_cull_instances), or nullptr: the
+                                 // workgroup builds its instance's composites in LDS (a single model)
+    uint2* work_list;            // see GeomParams
+    uint32_t* work_counts;
+    uint32_t work_nsub, work_sub_cap;
+    uint32_t keep_all;           // timing ablation (MTR_CULL_DEBUG=3): run the tests, keep everything
+};
+void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t s);

@@ -7,6 +7,8 @@ namespace mtr {
 
 // every workgroup of a tile kernel clears its slice of the counter block the next frame on these framebuffers will use
 __device__ __forceinline__ void zero_next_counters(const TileParams& P) {
+    if (P.zero_words)
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.zero_nwords; i += gridDim.x * blockDim.x) P.zero_words[i] = 0u;
     if (!P.zero_next) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)CTR_NUM; i += gridDim.x * blockDim.x) P.zero_next[i] = 0u;
 }

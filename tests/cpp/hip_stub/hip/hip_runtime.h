@@ -46,3 +46,5 @@ inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) { *dp = hp; return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }

@@ -93,6 +93,7 @@ def test_every_ownership_map_rebuilds_the_unsharded_frame(gpu_device, name, own_
         if rank == world - 1:
             gathered = torch.cat(shards)
             out = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # torch's stream made them; the unpack runs on the device's own (non-blocking) stream
             fr.unpack_color_shards(gathered.data_ptr(), out.data_ptr())
             torch.cuda.synchronize()
             assert (out.cpu().numpy().reshape(h, w, 4) == full[0]).all(), (name, world)
