@@ -256,13 +256,17 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8) | (dmat.translucent << 16);
     r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
     if (n_out >= 1) {
-        P.fb.rec_a[base + rank] = r0.a;
+        const bool lg = rec_is_large(r0.a);
+        P.fb.rec_a[base + rank] = rec_pack(r0.a, lg);
+        if (lg) P.fb.rec_l[base + rank] = make_int4(r0.a.X1, r0.a.Y1, r0.a.X2, r0.a.Y2);
         if (MODE == 0) P.fb.rec_hdr[base + rank] = r0.h;  // read back by k_fill only
         if (want_b) P.fb.rec_b[base + rank] = r0.b;
         s_hdr[rank] = r0.h;
     }
     if (n_out == 2) {
-        P.fb.rec_a[base + rank + 1] = r1.a;
+        const bool lg = rec_is_large(r1.a);
+        P.fb.rec_a[base + rank + 1] = rec_pack(r1.a, lg);
+        if (lg) P.fb.rec_l[base + rank + 1] = make_int4(r1.a.X1, r1.a.Y1, r1.a.X2, r1.a.Y2);
         if (MODE == 0) P.fb.rec_hdr[base + rank + 1] = r1.h;
         if (want_b) P.fb.rec_b[base + rank + 1] = r1.b;
         s_hdr[rank + 1] = r1.h;

@@ -55,7 +55,7 @@ enum { TF_LARGE = 1, TF_TEX = 2, TF_BLEND = 4 };
 template <bool TEX>
 __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriC& t, TriX* x,
                                             int4& chi, uint32_t& submask) {
-    const RecA a = P.fb.rec_a[r];
+    const RecA a = load_rec(P.fb, r);
     const uint32_t mshader = a.pad1 & 0xffu, mblend = (a.pad1 >> 8) & 0xffu;
     const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
     const long long A2 = (long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]);

@@ -209,11 +209,11 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         if (first + stride + lane < N) ord_nxt = P.fb.entries[ent_lo + first + stride + lane];
     }
     RecA a_cur = zero_rec;
-    if (first + lane < N) a_cur = P.fb.rec_a[(ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u)];
+    if (first + lane < N) a_cur = load_rec(P.fb, (ord_cur >> 7) * MTR_CHUNK_SLOTS + (ord_cur & 127u));
     for (uint32_t e0 = first; e0 < N; e0 += stride) {
         const bool valid = e0 + lane < N;
         RecA a_nxt = zero_rec;
-        if (e0 + stride + lane < N) a_nxt = P.fb.rec_a[(ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u)];
+        if (e0 + stride + lane < N) a_nxt = load_rec(P.fb, (ord_nxt >> 7) * MTR_CHUNK_SLOTS + (ord_nxt & 127u));
         uint32_t ord_nn = 0;
         if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
@@ -345,14 +345,14 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             dep = __uint_as_float(~(uint32_t)(key >> 32));
             const uint32_t ord = (uint32_t)key - 1u;
             const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
-            // third 16-byte word of the record: {z2, material id, material rgba8, shader | blend << 8}
-            const uint4 tail = reinterpret_cast<const uint4*>(&P.fb.rec_a[r])[2];
-            if (TEX && (tail.w & 0xffu) == MTR_SH_TEXTURED) {
-                const RecA a = P.fb.rec_a[r];
+            // the last word of the record: the source colour of a solid triangle (top byte 0xFF) or a material id
+            const uint32_t payload = P.fb.rec_a[r].q1.w;
+            if (TEX && (payload >> 24) != 0xFFu) {
+                const RecA a = load_rec(P.fb, r);
                 const RecB b = P.fb.rec_b[r];
-                col = shade_textured(a, b, P.mats[tail.y], (int32_t)x, (int32_t)y);
+                col = shade_textured(a, b, P.mats[a.mat], (int32_t)x, (int32_t)y);
             } else {
-                col = tail.z;
+                col = payload;
             }
         }
         const size_t pi = (size_t)y * P.fb.W + x;

@@ -50,7 +50,8 @@ struct ColorDepth {
 #define MTR_MAX_SLOTS 8
 struct Slot {
     RecHdr* rec_hdr = nullptr;
-    RecA* rec_a = nullptr;
+    RecP* rec_a = nullptr;
+    int4* rec_l = nullptr;
     RecB* rec_b = nullptr;
     ChunkInfo* chunk_info = nullptr;
     uint32_t rec_cap = 0, chunk_cap = 0;
@@ -749,7 +750,7 @@ void mtr_device_destroy(mtr_device* d) {
         if (f.done) (void)hipEventDestroy(f.done);
     }
     for (Slot& sl : d->slots) {
-        void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
+        void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_l, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
                         sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count, sl.work_list, sl.comp};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -1358,6 +1359,7 @@ static int32_t run_frame(mtr_frame* f) {
         uint32_t c0 = sl.rec_cap, c1 = sl.rec_cap, c2 = sl.rec_cap;
         if ((rc = dev_grow(d, &sl.rec_hdr, &c0, rec_need))) return rc;
         if ((rc = dev_grow(d, &sl.rec_a, &c1, rec_need))) return rc;
+        { uint32_t c3 = sl.rec_cap; if ((rc = dev_grow(d, &sl.rec_l, &c3, rec_need))) return rc; }
         if ((rc = dev_grow(d, &sl.rec_b, &c2, rec_need))) return rc;
         sl.rec_cap = c0;
     }
@@ -1432,6 +1434,7 @@ static int32_t run_frame(mtr_frame* f) {
                 mats.push_back(dm);
             }
     }
+    if (mats.size() >= MTR_MAX_TEXTURED_MATERIALS) return fail(d, MTR_E_OVERFLOW, "too many materials in one frame (a record holds a 24-bit material id)");
     if (mats.size() > sl.mat_cap || !sl.mats) {
         HIPCHK(d, hipStreamSynchronize(sl.stream));
         if ((rc = dev_grow(d, &sl.mats, &sl.mat_cap, std::max<size_t>(mats.size(), 64)))) return rc;
@@ -1445,7 +1448,7 @@ static int32_t run_frame(mtr_frame* f) {
     }
 
     FrameBuffers fb{};
-    fb.rec_hdr = sl.rec_hdr; fb.rec_a = sl.rec_a; fb.rec_b = sl.rec_b; fb.chunk_info = sl.chunk_info;
+    fb.rec_hdr = sl.rec_hdr; fb.rec_a = sl.rec_a; fb.rec_l = sl.rec_l; fb.rec_b = sl.rec_b; fb.chunk_info = sl.chunk_info;
     fb.bin_count = sl.bin_count; fb.bin_fill = sl.bin_fill; fb.bin_start = sl.bin_start; fb.seg_start = sl.seg_start;
     fb.entries = sl.entries; fb.segs = sl.segs; fb.counters = f->fb.live();
     fb.rec_cap = sl.rec_cap; fb.entry_cap = sl.entry_cap; fb.seg_cap = sl.seg_cap;

@@ -78,7 +78,7 @@ struct DMat {            // one per (draw, [instance,] primitive)
 struct RecHdr {          // 8 B: bins covered, inclusive
     uint16_t bx0, by0, bx1, by1;
 };
-struct RecA {            // 48 B: what coverage + depth need
+struct RecA {            // what coverage + depth need, in registers (see RecP for the 32 bytes in memory)
     int32_t X0, Y0, X1, Y1;
     int32_t X2, Y2;
     float z0, z1;
@@ -86,6 +86,50 @@ struct RecA {            // 48 B: what coverage + depth need
     uint32_t mat;
     uint32_t pad0, pad1;  // pad0 = material rgba8 (debug / overlay colour), pad1 = shader | blend << 8 | translucent << 16
 };
+// RecA as it lives in HBM: 32 B.  A surviving triangle is written once by k_geom and read once per bin it touches by
+// the tile kernel (692 k reads per headline frame), so the record is what both kernels' traffic is made of.
+//   q0 = { X0, Y0, dX1 | dY1 << 16, dX2 | dY2 << 16 }   vertex 1 / 2 relative to vertex 0, 16 bits each (24.8 fixed
+//        point: up to 128 px); a triangle with a longer edge stores dX1 = -32768 and its four coordinates in rec_l[]
+//   q1 = { z0, z1, z2, payload }
+//   payload: top byte 0xFF = the quantised source colour of a debug-id / overlay triangle (their alpha is 1); otherwise
+//            a textured triangle: material id (24 bits) | blend << 24 | translucent << 25
+struct RecP {
+    uint4 q0, q1;
+};
+#define MTR_REC_LARGE_SENTINEL 0x8000u
+#define MTR_MAX_TEXTURED_MATERIALS (1u << 24)
+
+__device__ __forceinline__ bool rec_is_large(const RecA& a) {
+    const int32_t d1x = a.X1 - a.X0, d1y = a.Y1 - a.Y0, d2x = a.X2 - a.X0, d2y = a.Y2 - a.Y0;
+    return d1x < -32767 || d1x > 32767 || d1y < -32767 || d1y > 32767 || d2x < -32767 || d2x > 32767 || d2y < -32767 || d2y > 32767;
+}
+__device__ __forceinline__ RecP rec_pack(const RecA& a, bool large) {
+    RecP p;
+    const uint32_t shader = a.pad1 & 0xffu, blend = (a.pad1 >> 8) & 1u, transl = (a.pad1 >> 16) & 1u;
+    const uint32_t payload = shader == MTR_SH_TEXTURED ? ((a.mat & 0xFFFFFFu) | (blend << 24) | (transl << 25)) : (a.pad0 | 0xFF000000u);
+    const uint32_t d1 = large ? MTR_REC_LARGE_SENTINEL : (((uint32_t)(a.X1 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y1 - a.Y0) << 16));
+    const uint32_t d2 = large ? 0u : (((uint32_t)(a.X2 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y2 - a.Y0) << 16));
+    p.q0 = make_uint4((uint32_t)a.X0, (uint32_t)a.Y0, d1, d2);
+    p.q1 = make_uint4(__float_as_uint(a.z0), __float_as_uint(a.z1), __float_as_uint(a.z2), payload);
+    return p;
+}
+// `l`: the record's entry of rec_l[] (read by the caller only when (q0.z & 0xFFFF) == MTR_REC_LARGE_SENTINEL)
+__device__ __forceinline__ RecA rec_unpack(const RecP& p, const int4& l) {
+    RecA a;
+    a.X0 = (int32_t)p.q0.x; a.Y0 = (int32_t)p.q0.y;
+    if ((p.q0.z & 0xFFFFu) == MTR_REC_LARGE_SENTINEL) {
+        a.X1 = l.x; a.Y1 = l.y; a.X2 = l.z; a.Y2 = l.w;
+    } else {
+        a.X1 = a.X0 + (int32_t)(int16_t)(p.q0.z & 0xFFFFu); a.Y1 = a.Y0 + ((int32_t)p.q0.z >> 16);
+        a.X2 = a.X0 + (int32_t)(int16_t)(p.q0.w & 0xFFFFu); a.Y2 = a.Y0 + ((int32_t)p.q0.w >> 16);
+    }
+    a.z0 = __uint_as_float(p.q1.x); a.z1 = __uint_as_float(p.q1.y); a.z2 = __uint_as_float(p.q1.z);
+    const uint32_t pl = p.q1.w;
+    if ((pl >> 24) == 0xFFu) { a.mat = 0; a.pad0 = pl; a.pad1 = MTR_SH_DEBUG | (1u << 8); }
+    else { a.mat = pl & 0xFFFFFFu; a.pad0 = 0; a.pad1 = MTR_SH_TEXTURED | (((pl >> 24) & 1u) << 8) | (((pl >> 25) & 1u) << 16); }
+    return a;
+}
+
 struct RecB {            // 48 B: perspective-correct texcoords (textured primitives only)
     float iw0, iw1, iw2, up0;
     float up1, up2, vp0, vp1;
@@ -155,7 +199,8 @@ enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_SHARD_BASE = 32, CTR
 
 struct FrameBuffers {
     RecHdr* rec_hdr;
-    RecA* rec_a;
+    RecP* rec_a;      // packed records
+    int4* rec_l;      // X1, Y1, X2, Y2 of the records whose edges do not fit 16-bit deltas (same index)
     RecB* rec_b;
     ChunkInfo* chunk_info;
     unsigned long long* bin_count;  // lo32 entries, hi32 segments

@@ -25,6 +25,14 @@ __device__ __forceinline__ uint32_t tile_prologue(const TileParams& P) {
     return ovf;
 }
 
+// one record, decoded (the rare long-edged triangle costs a second, dependent load)
+__device__ __forceinline__ RecA load_rec(const FrameBuffers& fb, uint32_t r) {
+    const RecP p = fb.rec_a[r];
+    int4 l = make_int4(0, 0, 0, 0);
+    if ((p.q0.z & 0xFFFFu) == MTR_REC_LARGE_SENTINEL) l = fb.rec_l[r];
+    return rec_unpack(p, l);
+}
+
 // byte / 255, bit-identical to the IEEE division SPEC.md spells, in three instructions instead of the ten of the
 // correctly rounded divide expansion: q0 = x * r, e = fma(-q0, 255, x), q = fma(e, r, q0), r = RN(1 / 255).  Verified
 // for all 256 bytes with exact rational arithmetic (tests/test_div_exact.py; the bare product x * r is wrong for 126

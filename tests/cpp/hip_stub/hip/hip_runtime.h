@@ -48,3 +48,9 @@ inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) { *dp =
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned a, unsigned b) { uint2 r = {a, b}; return r; }
+struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
+inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { uint4 r = {a, b, c, d}; return r; }
+inline int4 make_int4(int a, int b, int c, int d) { int4 r = {a, b, c, d}; return r; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
