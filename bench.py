@@ -24,22 +24,43 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# HBM bytes per launch of the two heaviest kernels on the headline scene, from rocprofv3 PMC passes run separately
-# (`--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B,
-# MI355X_MICROARCH.md "HBM").  Raw per-kernel means are committed in profiles/ (r01_d_pmc_headline.csv).
-TRAFFIC_TILE_VIS = 55451238     # k_tile_vis<false>: 2 x 18507.9 KB fetched + 17135.8 KB written (framebuffer = 16.6 MB)
-TRAFFIC_GEOM_DIRECT = 61785498  # k_geom<2>:         2 x 8939.4 KB fetched + 42458.6 KB written (records, bin queues, scratch)
+# roofline.traffic: HBM bytes per launch of the hot kernels from rocprofv3 PMC passes run separately (`--pmc FETCH_SIZE`,
+# then `--pmc WRITE_SIZE`; KB units; FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md
+# "HBM").  The numbers live in a tracked file, profiles/pmc_traffic.json, written by tools/profile_round.sh together
+# with a hash of the kernel sources they were measured on; a build whose sources hash differently reports null.
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def kernel_source_hash():
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mt_renderer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mt_renderer_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """{kernel name: HBM bytes per launch} for this build's kernels, or {} when the tracked measurement is of other sources"""
+    try:
+        d = json.load(open(PMC_TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return {}
+    return d.get("bytes_per_launch", {}) if d.get("kernel_source_hash") == kernel_source_hash() else {}
 
 
 def algorithmic_bytes(md, width, height, npalettes, nbones=64):
-    """B = V*stride + I*2 + W*H*(4+4) + N_pal*J*64 (+ T_unique, 0 for the debug-id shader)."""
+    """B = V*stride + I*2 + W*H*(4+4) + N_pal*J*64 (+ T_unique, 0 for the debug-id shader), and its
+    split over the two kernels: geometry reads vertices + indices + palettes, the tile kernel writes the framebuffer."""
     from mt_renderer_amd.scene import unpack_primitive
     v = i = 0
     for p in range(md.nprims):
         f = unpack_primitive(md.prims[p])
         v += f["vertex_num"] * f["vertex_stride"]
         i += f["index_num"] * 2
-    return v + i + width * height * 8 + npalettes * nbones * 64
+    geom, tile = v + i + npalettes * nbones * 64, width * height * 8
+    return geom + tile, geom, tile
 
 
 def main():
@@ -107,12 +128,33 @@ def main():
     # render streams and a frame took 0.089 ms instead of 0.057 (tools/probe/nccl_one_rank.py), hence
     # GPU_MAX_HW_QUEUES=8 above.  Rotating several exchange streams was measured too and is worse (more queues to share).
     shard = gathered = final = None
+    own = None  # (map, param, band rows) of the sharded frames
+    if sharded:
+        # Ownership: bands of bin rows (MTR_OWN_BANDS), so that a rank only processes the geometry that can reach its
+        # band (the library culls the rest before any vertex work), balanced by one unsharded calibration frame: every
+        # rank renders it, reads the queue length of each bin and cuts the rows into `world` bands of equal weight
+        # (entries + a constant per bin).  The counts are exact integers, so every rank derives the same bands without
+        # talking to the others.  MTR_BENCH_OWNERSHIP=interleaved|bands|supertiles overrides.
+        from mt_renderer_amd import sharding
+        kind = os.environ.get("MTR_BENCH_OWNERSHIP", "bands-balanced")
+        if kind == "interleaved":
+            own = (api.OWN_INTERLEAVED, 0, None)
+        elif kind == "supertiles":
+            own = (api.OWN_SUPERTILES, 3, None)
+        elif kind == "bands":
+            own = (api.OWN_BANDS, 0, sharding.equal_bands(H, world))
+        else:
+            fr = api.Frame(dev, W, H); model.render(fr, M); fr.end()
+            entries, _ = fr.bin_counts()
+            fr.close()
+            nbx, nby, _ = sharding.grid(W, H)
+            own = (api.OWN_BANDS, 0, sharding.balanced_bands(entries.reshape(nby, nbx).sum(axis=1).astype(np.float64) + 8.0 * nbx, world))
     rc = None  # direct RCCL communicator (mt_renderer_amd/rccl.py), or None: torch.distributed's collective
     xthread = False  # the exchange runs on the library's exchange thread
     xstream = None
     lane2 = None  # second exchange lane: (communicator, send, gathered, final, stream)
     if sharded:
-        nbytes = int(api.lib.mtr_shard_bytes(W, H, world))
+        nbytes = api.shard_bytes_map(W, H, world, *own)
         shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         gathered = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
         final = torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")
@@ -201,10 +243,17 @@ def main():
                         xthread = False
                         lane2 = None
 
+    # the timed loop body with every argument marshalled once (api.FrameLoop): begin -> set_shard -> draw -> submit
+    # [-> hand-over to the exchange thread] -> destroy, the same C calls as the classes make
+    loop = api.FrameLoop(dev, W, H, model=model, view_proj=M, shard=(rank, world) + own if sharded else None, exchange=xthread)
+
     def one_frame(check=False):
+        if not check and (xthread or not sharded):
+            loop.run(1)
+            return
         fr = api.Frame(dev, W, H)
         if sharded:
-            fr.set_shard(rank, world)
+            fr.set_shard(rank, world, *own)
         model.render(fr, M)
         if check or not xthread:
             fr.submit()
@@ -227,13 +276,14 @@ def main():
                     host = torch.empty(gathered.numel(), dtype=torch.uint8)
                     dist.all_gather_into_tensor(host, shard.cpu())
                     gathered.copy_(host)
-            dev.unpack_color_shards(gathered.data_ptr(), world, W, H, final.data_ptr())
+            fr.unpack_color_shards(gathered.data_ptr(), final.data_ptr())
         fr.close()
 
     def sync():
         if xthread:
             dev.exchange_drain()  # every handed-over frame has been issued
         torch.cuda.synchronize()
+        dev.synchronize()  # raises if a frame nobody waited for overflowed its bin queues (it would be missing triangles)
         if sharded:
             dist.barrier()
             torch.cuda.synchronize()
@@ -254,8 +304,11 @@ def main():
         one_frame()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_frame()
+    if xthread or not sharded:
+        loop.run(args.steps)
+    else:
+        for _ in range(args.steps):
+            one_frame()
     sync()
     dt = time.perf_counter() - t0
     if sharded:
@@ -279,17 +332,28 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     mtris = ntris / (ms_per_step * 1e-3) / 1e6
 
-    # ---- roofline: per-stage hipEvent timing on the library's stream, separate from the timed region ----
-    # Same submission pattern as the timed region (frames in flight on the library's internal streams, nothing waited
+    # ---- roofline: per-stage hipEvent timing on the library's streams, separate from the timed region ----
+    # (1) Same submission pattern as the timed region (frames in flight on the library's internal streams, nothing waited
     # until several later frames are queued), with hipEvents around every kernel of every frame: the averages are the
     # kernels' launch durations WHILE OVERLAPPING, which is what rocprofv3 --kernel-trace --stats reports for the
-    # same command (profiles/).  stage_ms_serial: the same kernels one frame at a time (nothing else on the GPU).
+    # same command (profiles/).  (2) The same kernels one frame at a time, nothing else on the GPU: 60 frames, of which
+    # the per-kernel stand-alone durations and the SURVEY 8(d) latency are the medians -- ms/frame from
+    # mtr_frame_begin (clear fused into the tile kernel) to the framebuffer complete in HBM, by the events that bracket
+    # the frame's first and last kernel, and by the host's clock around begin .. wait.
     dev.set_profiling(True)
     stage_ms = {k: 0.0 for k in api.STAGE_NAMES}
     nprof = max(8, min(100, args.steps))
     depth = 6
     stats = None
     inflight = []
+    shard_args = (rank, world) + own if sharded else None
+
+    def new_frame():
+        fr = api.Frame(dev, W, H)
+        if sharded:
+            fr.set_shard(*shard_args)
+        model.render(fr, M)
+        return fr
 
     def retire(fr):
         nonlocal stats
@@ -300,43 +364,64 @@ def main():
         fr.close()
 
     for _ in range(nprof):
-        fr = api.Frame(dev, W, H)
-        if sharded:
-            fr.set_shard(rank, world)
-        model.render(fr, M)
+        fr = new_frame()
         fr.submit()
         inflight.append(fr)
         if len(inflight) > depth:
             retire(inflight.pop(0))
     while inflight:
         retire(inflight.pop(0))
-    stage_ms_serial = {k: 0.0 for k in api.STAGE_NAMES}
-    for _ in range(10):
-        fr = api.Frame(dev, W, H)
-        if sharded:
-            fr.set_shard(rank, world)
-        model.render(fr, M)
+    serial = {k: [] for k in api.STAGE_NAMES}
+    lat_gpu, lat_host = [], []
+    for it in range(65):
+        t1 = time.perf_counter()
+        fr = new_frame()
         fr.end()
-        for k, v in fr.timings_ms().items():
-            stage_ms_serial[k] += v / 10
+        t2 = time.perf_counter()
+        tm = fr.timings_ms()
         fr.close()
+        if it >= 5:
+            for k, v in tm.items():
+                serial[k].append(v)
+            lat_gpu.append(sum(tm.values()))
+            lat_host.append((t2 - t1) * 1e3)
     dev.set_profiling(False)
-    dom = max(stage_ms, key=lambda k: stage_ms[k])
-    alg_bytes = algorithmic_bytes(md, W, H, 1)
-    achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    kname = {"geom": "k_geom<%d>" % ((2 if stats["tile_kernel"] == 2 else 1) if stats["binning"] == 1 else 0), "scan": "k_scan", "fill": "k_fill",
-             "tile": "k_tile_vis<false>" if stats["tile_kernel"] == 2 else "k_tile<false>"}[dom]
-    # HBM bytes of that kernel per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-    # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md); measured offline, see profiles/README.md
-    traffic = {"k_tile_vis<false>": TRAFFIC_TILE_VIS, "k_geom<2>": TRAFFIC_GEOM_DIRECT}.get(kname) if world == 1 else None
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 5),
+    med = lambda xs: float(np.median(xs))
+    stage_ms_serial = {k: med(v) for k, v in serial.items()}
+    alg_frame, alg_geom, alg_tile = algorithmic_bytes(md, W, H, 1)
+    direct = stats["binning"] == 1
+    vis = stats["tile_kernel"] == 2
+    names = {"geom": "k_geom<%d, %s>" % (((2 if vis else 1) if direct else 0), "true" if sharded and own[0] != api.OWN_INTERLEAVED else "false"),
+             "scan": "k_scan", "fill": "k_fill", "tile": ("k_tile_vis<false, %d>" % (2 if stats["shard_bins"] > 4096 else (4 if stats["shard_bins"] > 1536 else 8))) if vis else "k_tile<false>"}
+    alg = {"geom": alg_geom, "tile": alg_tile}
+    traffic_by_kernel = pmc_traffic() if world == 1 else {}
+    kernels = {}
+    for st in ("geom", "tile"):
+        k = {"kernel": names[st], "algorithmic_bytes_per_launch": alg[st], "ms_overlapped": round(stage_ms[st], 5),
+             "ms_standalone": round(stage_ms_serial[st], 5), "traffic": traffic_by_kernel.get(names[st])}
+        k["frac_overlapped"] = round(alg[st] / (stage_ms[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        k["frac_standalone"] = round(alg[st] / (stage_ms_serial[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        kernels[st] = k
+    dom = max(("geom", "tile"), key=lambda k: stage_ms[k])
+    achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    # achieved / frac: the dominant kernel's OWN algorithmic bytes over its average launch duration in the pipelined
+    # pattern of the timed region (what rocprofv3 --stats of this command reports); `kernels` has both kernels, each
+    # also against its stand-alone duration; `frame_*`: the whole frame's algorithmic bytes over the measured ms_per_step
+    roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": kernels[dom]["traffic"],
+                "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage_ms[dom], 5),
+                "kernels": kernels,
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                 "stage_ms_serial": {k: round(v, 5) for k, v in stage_ms_serial.items()},
-                "frame_gbps": round(alg_bytes / (ms_per_step * 1e-3) / 1e9, 3)}
-    if stats["binning"] == 1:  # single-pass binning: k_scan / k_fill are not launched at all
-        roofline["stage_note"] = "single-pass binning: no k_scan / k_fill launch; their entries are the gap between two timing events recorded back to back"
+                "frame_algorithmic_bytes": alg_frame,
+                "frame_gbps": round(alg_frame / (ms_per_step * 1e-3) / 1e9, 3),
+                "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic_source": ("profiles/pmc_traffic.json (kernel sources %s)" % kernel_source_hash()) if traffic_by_kernel else None}
+    if direct:  # single-pass binning: k_scan / k_fill are not launched at all
+        roofline["stage_note"] = "single-pass binning: no k_scan / k_fill launch (reported as 0)" + \
+                                 ("; sharded frames: the geom stage includes the culling kernels" if sharded else "")
+    latency = {"ms_per_frame_latency": round(med(lat_gpu), 5), "frames": len(lat_gpu), "definition": "SURVEY 8(d): one frame at a time, first kernel start to framebuffer complete in HBM (hipEvents on the frame's stream), median",
+               "ms_per_frame_latency_host_clock": round(med(lat_host), 5), "mtris_per_s_at_latency": round(ntris / (med(lat_gpu) * 1e-3) / 1e6, 2)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -366,8 +451,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
                                    "64-bone palette, debug-id shader, %dx%d" % (W, H),
-                       "triangles_per_frame": ntris, "sharding": "bins %% %d" % world if sharded else "none",
+                       "triangles_per_frame": ntris,
+                       "sharding": ({api.OWN_INTERLEAVED: "bins %% %d" % world, api.OWN_BANDS: "bands of bin rows %s over %d ranks, geometry culled per rank" % (list(map(int, own[2])) if own[2] is not None else "equal", world),
+                                     api.OWN_SUPERTILES: "super-tiles of %d x %d bins over %d ranks, geometry culled per rank" % (1 << own[1], 1 << own[1], world)}[own[0]]) if sharded else "none",
                        "collective": ((("ncclAllGather (exchange thread, 2 lanes)" if lane2 is not None else "ncclAllGather (exchange thread)") if xthread else "ncclAllGather (ctypes)") if rc is not None else "torch.distributed all_gather_into_tensor") if sharded else "none"},
+            "value_is": "pipelined throughput: frames submitted back to back, three in flight on the library's streams; the per-frame latency is in `latency`",
+            "latency": latency,
             "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(out))

@@ -1598,10 +1598,12 @@ static int32_t run_frame(mtr_frame* f) {
         chunk_base += gp.nchunks * dr.ninst;
     }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[1], sg));
+    // single-pass binning launches neither kernel: no event either (an event costs the stream ~5 us, which would count
+    // as frame latency); mtr_frame_wait reports both stages as 0
     if (!fb.direct) mtr_launch_scan(fb, sg);
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[2], sg));
+    if (prof && !fb.direct) HIPCHK(d, hipEventRecord(f->ev[2], sg));
     if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, sg);
-    if (prof) HIPCHK(d, hipEventRecord(f->ev[3], st));
+    if (prof && !fb.direct) HIPCHK(d, hipEventRecord(f->ev[3], st));
     TileParams tp{};
     tp.fb = fb; tp.mats = sl.mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
     tp.clear_rgba8 = f->clear_rgba8; tp.clear_depth = f->clear_depth;
@@ -1717,8 +1719,15 @@ int32_t mtr_frame_wait(mtr_frame* f) {
     // wait for THIS frame only (the public stream also carries the completion of every later frame)
     if ((rc = settle_frame(f, true))) return rc;
     HIPCHK(d, hipEventSynchronize(f->fb.done));  // of the last run
-    if (d->profiling && f->have_events)
-        for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
+    if (d->profiling && f->have_events) {
+        if (f->ran_direct) {
+            HIPCHK(d, hipEventElapsedTime(&f->ms[MTR_STAGE_GEOM], f->ev[0], f->ev[1]));
+            f->ms[MTR_STAGE_SCAN] = f->ms[MTR_STAGE_FILL] = 0.0f;
+            HIPCHK(d, hipEventElapsedTime(&f->ms[MTR_STAGE_TILE], f->ev[1], f->ev[4]));
+        } else {
+            for (int s = 0; s < MTR_STAGE_COUNT; s++) HIPCHK(d, hipEventElapsedTime(&f->ms[s], f->ev[s], f->ev[s + 1]));
+        }
+    }
     f->waited = true;
     return MTR_OK;
 }

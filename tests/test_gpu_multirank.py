@@ -21,4 +21,16 @@ def test_two_ranks_one_gpu_gathered_frame_matches_unsharded():
     assert r.stderr.count("verify gathered frame == unsharded frame: True") == 2, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["sharding"] == "bins % 2"
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["sharding"].startswith("bands of bin rows [0, ")
+    assert out["frame_stats"]["chunks_culled"] > 0  # rank 0 skipped the geometry of the other rank's band
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ownership", ["interleaved", "supertiles"])
+def test_two_ranks_one_gpu_other_ownership_maps(ownership):
+    env = dict(os.environ, MTR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MTR_BENCH_OWNERSHIP=ownership)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--verify"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count("verify gathered frame == unsharded frame: True") == 2, r.stderr[-2000:]

@@ -14,4 +14,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $d -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $d/log.txt 2>&1 || echo "pass failed: $grp"
 done
 cd $R && python tools/pmc_summary.py gpurun_out/${T}_pmc/* > gpurun_out/${T}_pmc_headline.csv
+python tools/pmc_traffic_json.py gpurun_out/${T}_pmc ${T} gpurun_out/${T}_pmc_traffic.json  # -> profiles/pmc_traffic.json (bench.py reads it)
 cat gpurun_out/${T}_bench_line.json; head -6 gpurun_out/${T}_kernel_stats_headline.csv; cat gpurun_out/${T}_pmc_headline.csv
