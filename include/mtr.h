@@ -54,11 +54,15 @@ typedef struct mtr_primitive {
 
 /* one decoded input-layout element (src/rshader2.rs:425-442): replaces the wgpu::VertexAttribute
  * list that Shader2File::create_vertex_buffer_elements builds (src/rshader2.rs:496-571) */
+/* mtr_element.flags: the reference skips IEF_SCMP3N elements (src/rshader2.rs:509-512); with this bit a Position /
+ * TexCoord element of that format is decoded as three signed 10-bit fields, x = bits 0..9, max(v / 511, -1)
+ * (build extension, row f-4; SPEC.md section 2) */
+#define MTR_ELEM_DECODE_SCMP3N 1u
 typedef struct mtr_element {
     uint8_t semantic; /* MTR_SEM_* */
     uint8_t format;   /* MTR_IEF_* */
     uint8_t count;
-    uint8_t pad0;
+    uint8_t flags;    /* MTR_ELEM_* (0 = the reference's behaviour) */
     uint16_t offset;  /* byte offset inside the vertex (9 bits in the file) */
     uint16_t pad1;
 } mtr_element;
@@ -120,8 +124,14 @@ int32_t mtr_abi_version(void);
 /* ---- Texture::new (src/texture.rs:11-30): level 0 only, 2-D, decoded on upload ---- */
 int32_t mtr_texture_create(mtr_device *dev, uint32_t width, uint32_t height, uint32_t format,
                            const void *data, size_t len, mtr_texture **out);
+/* the same with a mip chain (row f-4): `levels` levels in `data`, level l = max(1, width >> l) x max(1, height >> l),
+ * level 0 first, each in `format`.  The reference uploads level 0 only (src/texture.rs:21) although rTexture files
+ * carry the chain (src/rtexture.rs:111-130); with more levels a minified sample (SPEC.md section 7) takes the nearest
+ * texel of the nearest level: level l while max |d(uv)/d(xy)| * size > 2^(l - 1/2).  levels = 1 is mtr_texture_create. */
+int32_t mtr_texture_create_mips(mtr_device *dev, uint32_t width, uint32_t height, uint32_t format, uint32_t levels,
+                                const void *data, size_t len, mtr_texture **out);
 void mtr_texture_destroy(mtr_texture *tex);
-/* decoded RGBA8 texels (row-major, width*height*4 bytes): what the sampler reads */
+/* decoded RGBA8 texels of level 0 (row-major, width*height*4 bytes): what the sampler reads */
 int32_t mtr_texture_read_rgba8(mtr_texture *tex, void *out, size_t len);
 
 /* ---- Model::new (src/model.rs:36-293) ----
@@ -136,6 +146,24 @@ int32_t mtr_model_create(mtr_device *dev, const void *vertex_buf, size_t vertex_
                          mtr_texture *const *textures, size_t ntextures,
                          const uint32_t *prim_debug_id, mtr_model **out);
 void mtr_model_destroy(mtr_model *model);
+/* Material state per primitive (row f-4).  The reference builds every pipeline with one fixed state (alpha blend,
+ * depth LessEqual + write, cull back: src/model.rs:240-262) and only LOGS the blend / depth-stencil / rasterizer
+ * state objects a material names (src/rmaterial.rs:104-106, :211-230); applying them is this build's extension:
+ *   blend       MTR_BLEND_ALPHA  rgb = src * a + dst * (1 - a), alpha = src (the reference)
+ *               MTR_BLEND_OFF    replace
+ *               MTR_BLEND_ADD    rgb = src * a + dst, alpha = src
+ *   depth_write 1 (the reference) / 0: fragments that pass leave the depth buffer alone
+ *   depth_test  1: LessEqual (the reference) / 0: always pass (near / far clipping still applies)
+ *   cull        MTR_CULL_BACK (the reference) / MTR_CULL_NONE / MTR_CULL_FRONT; a back face that is kept is
+ *               rasterised with its second and third vertex exchanged
+ * states: nprims entries, or NULL to go back to the reference state.  Takes effect for frames drawn afterwards.
+ * mtr_files.h maps MT Framework state-object names to these (mtr_state_from_names). */
+enum { MTR_BLEND_ALPHA = 0, MTR_BLEND_OFF = 1, MTR_BLEND_ADD = 2 };
+enum { MTR_CULL_BACK = 0, MTR_CULL_NONE = 1, MTR_CULL_FRONT = 2 };
+typedef struct mtr_prim_state {
+    uint8_t blend, depth_write, depth_test, cull;
+} mtr_prim_state;
+int32_t mtr_model_set_prim_states(mtr_model *model, const mtr_prim_state *states, size_t nprims);
 /* Model::set_parts_disp (src/model.rs:295-297) */
 int32_t mtr_model_set_parts_disp(mtr_model *model, const uint8_t *parts_disp, size_t n);
 /* bone palette for linear-blend skinning (build extension; n x 16 f32 column-major, n <= 256) */

@@ -84,6 +84,11 @@ int32_t mtr_rtexture_parse(const void *data, size_t len, mtr_rtexture_view *out)
 /* TextureFile -> Texture::new -> mtr_texture_create in one call; MTR_E_UNSUPPORTED for a format
  * TextureFile::format_wgpu todo!()s */
 int32_t mtr_texture_create_from_file(mtr_device *dev, const void *data, size_t len, mtr_texture **out);
+/* the same with the file's mip chain (row f-4): the reference keeps every byte from the level-0 offset to the end of the
+ * file (src/rtexture.rs:129-130) and uploads level 0 only (src/texture.rs:21); here the offsets table (one u64 per level,
+ * src/rtexture.rs:111-126) locates up to max_levels levels of array slice 0, each checked to lie inside the file, and
+ * mtr_texture_create_mips samples them (SPEC.md section 7).  max_levels = 1 is mtr_texture_create_from_file. */
+int32_t mtr_texture_create_from_file_mips(mtr_device *dev, const void *data, size_t len, uint32_t max_levels, mtr_texture **out);
 
 /* -------------------------------------------------------------- rShader2 ---- */
 typedef struct mtr_rshader2 mtr_rshader2;
@@ -127,6 +132,24 @@ typedef struct mtr_material_info {
 int32_t mtr_rmaterial_info(const mtr_rmaterial *m, uint32_t i, mtr_material_info *out);
 /* MaterialFile::material_by_name (src/rmaterial.rs:304-311): index or -1 */
 int32_t mtr_rmaterial_find(const mtr_rmaterial *m, const char *name);
+
+/* Material state by name (row f-4).  The reference resolves a material's three state handles to shader-package objects
+ * and logs their NAMES (src/rmaterial.rs:211-230); it neither parses the objects' contents (OT_BLEND / OT_DEPTHSTENCIL
+ * / OT_RASTERIZER fall through `_ => None`, src/rshader2.rs:451) nor applies them.  MT Framework names its state objects
+ * by what they do, and this build maps the names it knows (a convention, not something the reference pins):
+ *   blend          "BSSolid" and names without "Blend"/"Add"/"Alpha" -> MTR_BLEND_OFF; names containing "Add" -> MTR_BLEND_ADD;
+ *                  other names containing "Blend" or "Alpha" -> MTR_BLEND_ALPHA
+ *   depth-stencil  depth_test = the name contains "ZTest"; depth_write = it contains "ZTestWrite" or "ZWrite"
+ *   rasterizer     names ending in "CN" or containing "CullNone" / "TwoSide" -> MTR_CULL_NONE; ending in "CF" or containing
+ *                  "CullFront" -> MTR_CULL_FRONT; otherwise MTR_CULL_BACK
+ * A NULL or empty name leaves the reference's state for that part.  Returns how many of the three names were recognised
+ * by an explicit rule (0..3) -- an unknown name maps to the default and is not counted. */
+int32_t mtr_state_from_names(const char *blend_name, const char *depth_stencil_name, const char *rasterizer_name, mtr_prim_state *out);
+/* per primitive of `model`: material name -> rMaterial entry -> its three state objects' names -> mtr_state_from_names.
+ * states: primitive_num entries (for mtr_model_set_prim_states); a primitive whose material is not in `mat` keeps the
+ * reference state. */
+int32_t mtr_model_states_from_files(const mtr_rmodel_view *model, const mtr_rshader2 *sh, const mtr_rmaterial *mat,
+                                    mtr_prim_state *states, size_t nstates);
 
 /* ------------------------------------------------------------ rScheduler ---- */
 typedef struct mtr_rscheduler mtr_rscheduler;

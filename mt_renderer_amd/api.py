@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_synchronize", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
+    "mtr_device_synchronize", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
     "mtr_frame_unpack_color_shards_on_stream", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
@@ -52,7 +52,7 @@ class _Primitive(C.Structure):
 
 
 class _Element(C.Structure):
-    _fields_ = [("semantic", C.c_uint8), ("format", C.c_uint8), ("count", C.c_uint8), ("pad0", C.c_uint8),
+    _fields_ = [("semantic", C.c_uint8), ("format", C.c_uint8), ("count", C.c_uint8), ("flags", C.c_uint8),
                 ("offset", C.c_uint16), ("pad1", C.c_uint16)]
 
 
@@ -94,6 +94,8 @@ def _load() -> C.CDLL:
         "mtr_device_set_profiling": (i32, [vp, i32]),
         "mtr_device_synchronize": (i32, [vp]),
         "mtr_texture_create": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(vp)]),
+        "mtr_texture_create_mips": (i32, [vp, u32, u32, u32, u32, vp, sz, C.POINTER(vp)]),
+        "mtr_model_set_prim_states": (i32, [vp, vp, sz]),
         "mtr_texture_destroy": (None, [vp]),
         "mtr_texture_read_rgba8": (i32, [vp, vp, sz]),
         "mtr_model_create": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, sz, vp, C.POINTER(vp)]),
@@ -253,8 +255,8 @@ class Texture:
         """Texture::new(device, queue, resource) -- src/texture.rs:11."""
         h = C.c_void_p()
         buf = np.frombuffer(resource.data, dtype=np.uint8)
-        dev.check(lib.mtr_texture_create(dev._h, resource.width, resource.height, resource.fmt, _p(buf), buf.size,
-                                         C.byref(h)))
+        dev.check(lib.mtr_texture_create_mips(dev._h, resource.width, resource.height, resource.fmt, getattr(resource, "levels", 1),
+                                              _p(buf), buf.size, C.byref(h)))
         t = Texture(dev, h)
         t.width, t.height = resource.width, resource.height
         return t
@@ -287,9 +289,10 @@ class Model:
             if len(els) > 8:
                 raise MtrError(MTR_E_INVALID, "more than 8 layout elements")
             lays[i].num_elements = len(els)
-            for j, (sem, fmt, cnt, off) in enumerate(els):
+            for j, el in enumerate(els):  # (semantic, format, count, offset[, flags])
                 e = lays[i].elements[j]
-                e.semantic, e.format, e.count, e.offset = sem, fmt, cnt, off
+                e.semantic, e.format, e.count, e.offset = el[:4]
+                e.flags = el[4] if len(el) > 4 else 0
         p2t = np.ascontiguousarray(md.prim_to_texture, dtype=np.int32)
         did = np.ascontiguousarray(md.prim_debug_id, dtype=np.uint32)
         th = (C.c_void_p * max(1, len(textures)))(*[t._h for t in textures])
@@ -300,7 +303,17 @@ class Model:
         pd = np.ascontiguousarray(md.parts_disp, dtype=np.uint8)
         if pd.size != pr.shape[0] or not pd.all():
             m.set_parts_disp(pd)
+        if getattr(md, "prim_states", None) is not None:
+            m.set_prim_states(md.prim_states)
         return m
+
+    def set_prim_states(self, states):
+        """material state per primitive: uint8 [nprims, 4] = blend, depth write, depth test, cull (include/mtr.h), or None"""
+        if states is None:
+            self.dev.check(lib.mtr_model_set_prim_states(self._h, None, 0))
+        else:
+            st = np.ascontiguousarray(states, dtype=np.uint8).reshape(-1, 4)
+            self.dev.check(lib.mtr_model_set_prim_states(self._h, _p(st), st.shape[0]))
 
     def set_parts_disp(self, parts_disp: Sequence[bool]):
         """Model::set_parts_disp -- src/model.rs:295."""

@@ -66,6 +66,13 @@ __device__ __forceinline__ void decode_elem(uint32_t fmt, uint32_t cnt, const ui
     case 1: /* F32 x3 */
         x = __uint_as_float(ld32(p, al4)); y = __uint_as_float(ld32(p + 4, al4)); z = __uint_as_float(ld32(p + 8, al4));
         break;
+    case 11: /* SCMP3N, opted into by MTR_ELEM_DECODE_SCMP3N: three signed 10-bit fields, max(v / 511, -1) */ {
+        const uint32_t w = ld32(p, al4);
+        const float fx = (float)((int32_t)(w << 22) >> 22) / 511.0f, fy = (float)((int32_t)(w << 12) >> 22) / 511.0f,
+                    fz = (float)((int32_t)(w << 2) >> 22) / 511.0f;
+        x = fx < -1.0f ? -1.0f : fx; y = fy < -1.0f ? -1.0f : fy; z = fz < -1.0f ? -1.0f : fz;
+        break;
+    }
     default: break;
     }
 }

@@ -64,11 +64,15 @@ struct Rec {
 };
 
 // back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill
-__device__ __forceinline__ bool setup_tri(const PV& a, const PV& b, const PV& c, uint32_t W, uint32_t H, uint32_t mat,
-                                          Rec& r) {
-    if (!((a.flags & b.flags & c.flags) & 2)) return false;
-    long long A2 = (long long)(c.X - a.X) * (long long)(b.Y - a.Y) - (long long)(b.X - a.X) * (long long)(c.Y - a.Y);
-    if (A2 <= 0) return false;
+__device__ __forceinline__ bool setup_tri(const PV& a, const PV& b_in, const PV& c_in, uint32_t W, uint32_t H, uint32_t mat,
+                                          uint32_t cull, Rec& r) {
+    if (!((a.flags & b_in.flags & c_in.flags) & 2)) return false;
+    long long A2 = (long long)(c_in.X - a.X) * (long long)(b_in.Y - a.Y) - (long long)(b_in.X - a.X) * (long long)(c_in.Y - a.Y);
+    // cull back (the reference) / none / front (material state): a kept back face is set up with b and c exchanged
+    if (cull == 0u ? A2 <= 0 : (A2 == 0 || (cull == 2u && A2 > 0))) return false;
+    const bool flip = A2 < 0;
+    const PV& b = flip ? c_in : b_in;
+    const PV& c = flip ? b_in : c_in;
     int32_t xmin = min(a.X, min(b.X, c.X)), xmax = max(a.X, max(b.X, c.X));
     int32_t ymin = min(a.Y, min(b.Y, c.Y)), ymax = max(a.Y, max(b.Y, c.Y));
     int32_t px0 = (xmin + 127) >> 8, px1 = (xmax - 128) >> 8;
@@ -194,7 +198,7 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     tri = tri && ((f_and >> 2) == 0);     // trivial frustum reject
     if (tri) {
         if (!((f_or >> 2) & OC_ZN)) {
-            if (setup_tri(ta, tb, tc, W, H, mat, r0)) n_out = 1;
+            if (setup_tri(ta, tb, tc, W, H, mat, pr.cull, r0)) n_out = 1;
         } else {
             // near-plane clip (z >= 0): rare, re-shades the three vertices in clip space
             const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
@@ -213,11 +217,11 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
             }
             if (n >= 3) {
                 PV q0 = project(poly[0], W, H), q1 = project(poly[1], W, H), q2 = project(poly[2], W, H);
-                bool s0 = setup_tri(q0, q1, q2, W, H, mat, r0);
+                bool s0 = setup_tri(q0, q1, q2, W, H, mat, pr.cull, r0);
                 bool s1 = false;
                 if (n == 4) {
                     PV q3 = project(poly[3], W, H);
-                    s1 = setup_tri(q0, q2, q3, W, H, mat, s0 ? r1 : r0);
+                    s1 = setup_tri(q0, q2, q3, W, H, mat, pr.cull, s0 ? r1 : r0);
                 }
                 n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
             }
@@ -252,8 +256,10 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     // texcoord planes are only read by textured materials: do not spend 48 B/triangle of HBM writes otherwise
     const DMat dmat = P.mats[mat];  // wave-uniform
     const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
-    // the fragment stage finds the source colour / shader class in the record itself: no dependent material lookup
-    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = dmat.shader | (dmat.blend << 8) | (dmat.translucent << 16);
+    // a solid colour in the default depth state replaces the pixel whatever the blend (its alpha is 1): the fragment
+    // stage finds the colour in the record itself, no dependent material lookup; everything else carries its material id
+    const uint32_t solid = (dmat.shader != MTR_SH_TEXTURED && dmat.blend != MTR_DB_ADD && dmat.dstate == 3u) ? 1u : 0u;
+    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = solid | ((dmat.blend != MTR_DB_OFF ? 1u : 0u) << 8) | (dmat.translucent << 16);
     r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
     if (n_out >= 1) {
         const bool lg = rec_is_large(r0.a);

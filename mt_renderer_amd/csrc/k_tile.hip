@@ -34,7 +34,8 @@ struct TriC {
     int32_t A0, B0, C0, A1;
     int32_t B1, C1, A2, B2;
     int32_t C2;
-    uint32_t flags;  // bit0 large, bit1 textured, bit2 blend, bits 4..6: (1 - tl_i), added back for barycentrics
+    uint32_t flags;  // bit0 large, bit1 textured, bit2 alpha blend, bit3 additive blend, bits 4..6: (1 - tl_i), added back
+                     // for barycentrics, bit7 no depth write, bit8 no depth test, bit9 colour through blend_store
     float z0, dz1;
     float dz2, rcpA;
     uint32_t rgba8;  // quantised source colour of the debug / constant shaders
@@ -44,19 +45,23 @@ struct TriX {
     float iw0, diw1, diw2, up0;
     float dup1, dup2, vp0, dvp1;
     float dvp2;
-    uint32_t tw, th, pad;
+    uint32_t tw, th, tlevels;
     const uint8_t* tex;
     uint64_t pad2;
 };
 static_assert(sizeof(TriC) == 64 && sizeof(TriX) == 64, "LDS triangle records are 64 B");
-enum { TF_LARGE = 1, TF_TEX = 2, TF_BLEND = 4 };
+enum { TF_LARGE = 1, TF_TEX = 2, TF_BLEND = 4, TF_ADD = 8, TF_NODW = 128, TF_NODT = 256, TF_BLENDSOLID = 512 };
 
 // per-entry set-up by one lane: record -> bin-relative edge equations in LDS
 template <bool TEX>
 __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int32_t binx0, int32_t biny0, TriC& t, TriX* x,
                                             int4& chi, uint32_t& submask) {
     const RecA a = load_rec(P.fb, r);
-    const uint32_t mshader = a.pad1 & 0xffu, mblend = (a.pad1 >> 8) & 0xffu;
+    // a solid record carries its colour and replaces the pixel; anything else names its material
+    const bool solid = (a.pad1 & 1u) != 0;
+    DMat mat = {};
+    if (!solid) mat = P.mats[a.mat];
+    const uint32_t mshader = solid ? (uint32_t)MTR_SH_DEBUG : mat.shader;
     const int32_t X[3] = {a.X0, a.X1, a.X2}, Y[3] = {a.Y0, a.Y1, a.Y2};
     const long long A2 = (long long)(X[2] - X[0]) * (long long)(Y[1] - Y[0]) - (long long)(X[1] - X[0]) * (long long)(Y[2] - Y[0]);
     const int32_t xmin = min(X[0], min(X[1], X[2])), xmax = max(X[0], max(X[1], X[2]));
@@ -79,14 +84,20 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
         Chi[i] = (int32_t)(C >> 32);
     }
     if (TEX && mshader == MTR_SH_TEXTURED) flags |= TF_TEX;
-    if (mblend) flags |= TF_BLEND;
+    if (!solid) {
+        if (mat.blend == MTR_DB_ALPHA) flags |= TF_BLEND;
+        if (mat.blend == MTR_DB_ADD) flags |= TF_ADD;
+        if (!(mat.dstate & 1u)) flags |= TF_NODW;
+        if (!(mat.dstate & 2u)) flags |= TF_NODT;
+        if (mshader != MTR_SH_TEXTURED && mat.blend == MTR_DB_ADD) flags |= TF_BLENDSOLID;
+    }
     t.A0 = A[0]; t.B0 = B[0]; t.C0 = Clo[0];
     t.A1 = A[1]; t.B1 = B[1]; t.C1 = Clo[1];
     t.A2 = A[2]; t.B2 = B[2]; t.C2 = Clo[2];
     t.flags = flags;
     t.z0 = a.z0; t.dz1 = a.z1 - a.z0; t.dz2 = a.z2 - a.z0;
     t.rcpA = 1.0f / (float)A2;
-    t.rgba8 = a.pad0;
+    t.rgba8 = solid ? a.pad0 : mat.rgba8;
     chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
     // sub-tiles (8x8 px) of this bin touched by the pixel-centre bbox: bit = sy*2 + sx
     int32_t px0 = ((xmin + 127) >> 8) - binx0, px1 = ((xmax - 128) >> 8) - binx0;
@@ -104,12 +115,11 @@ __device__ __forceinline__ void setup_entry(const TileParams& P, uint32_t r, int
         t.pad = (cx0 <= cx1 && cy0 <= cy1) ? ((uint32_t)cx0 | ((uint32_t)cy0 << 4) | ((uint32_t)(cx1 - cx0) << 8) | ((uint32_t)(cy1 - cy0) << 12) | (1u << 16)) : 0u;
     }
     if (TEX && mshader == MTR_SH_TEXTURED) {
-        const DMat mat = P.mats[a.mat];
         const RecB b = P.fb.rec_b[r];
         x->iw0 = b.iw0; x->diw1 = b.iw1 - b.iw0; x->diw2 = b.iw2 - b.iw0;
         x->up0 = b.up0; x->dup1 = b.up1 - b.up0; x->dup2 = b.up2 - b.up0;
         x->vp0 = b.vp0; x->dvp1 = b.vp1 - b.vp0; x->dvp2 = b.vp2 - b.vp0;
-        x->tex = mat.tex; x->tw = mat.tw; x->th = mat.th;
+        x->tex = mat.tex; x->tw = mat.tw; x->th = mat.th; x->tlevels = mat.tlevels;
     }
 }
 
@@ -340,10 +350,17 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                                     float b1, b2;
                                     bary(lx, ly, b1, b2);
                                     const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
-                                    if (!(z >= 0.0f && z <= 1.0f && z <= dep[i])) continue;
-                                    dep[i] = z;
+                                    if (!(z >= 0.0f && z <= 1.0f && ((flags & TF_NODT) || z <= dep[i]))) continue;
+                                    if (!(flags & TF_NODW)) dep[i] = z;
+                                    const uint32_t bmode = (flags & TF_ADD) ? 2u : ((flags & TF_BLEND) ? 1u : 0u);
                                     if (!TEX || !(flags & TF_TEX)) {
-                                        col[i] = (uint32_t)q3.z;
+                                        if (flags & TF_BLENDSOLID) {
+                                            const uint32_t c8 = (uint32_t)q3.z;
+                                            const float src[4] = {unorm8f(c8), unorm8f(c8 >> 8), unorm8f(c8 >> 16), unorm8f(c8 >> 24)};
+                                            col[i] = blend_store(col[i], src, bmode);
+                                        } else {
+                                            col[i] = (uint32_t)q3.z;
+                                        }
                                     } else {
                                         const TriX& Xt = s_tx[TEX ? best : 0];
                                         auto uv_at = [&](int32_t x, int32_t y, float& u, float& v) {
@@ -363,10 +380,10 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                                         uv_at(lx, ly ^ 1, uw, vw);
                                         const float dudx = (lx & 1) ? u - uh : uh - u, dvdx = (lx & 1) ? v - vh : vh - v;
                                         const float dudy = (ly & 1) ? u - uw : uw - u, dvdy = (ly & 1) ? v - vw : vw - v;
-                                        const TexRef tr = {Xt.tex, Xt.tw, Xt.th};
+                                        const TexRef tr = {Xt.tex, Xt.tw, Xt.th, Xt.tlevels};
                                         float src[4];
-                                        sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, tr.tw, tr.th), src);
-                                        col[i] = blend_store(col[i], src, (flags & TF_BLEND) != 0);
+                                        sample_texture(tr, u, v, filter_select(dudx, dvdx, dudy, dvdy, tr.tw, tr.th, tr.levels), src);
+                                        col[i] = blend_store(col[i], src, bmode);
                                     }
                                 }
                             }
@@ -412,9 +429,19 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                         }
                         const float b1 = e1f * rcpA, b2 = e2f * rcpA;
                         const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
-                        const bool pass = inside && in_vp && z >= 0.0f && z <= 1.0f && z <= dep[i];
+                        const bool pass = inside && in_vp && z >= 0.0f && z <= 1.0f && ((flags & TF_NODT) || z <= dep[i]);
+                        const uint32_t bmode = (flags & TF_ADD) ? 2u : ((flags & TF_BLEND) ? 1u : 0u);
                         if (!TEX || !(flags & TF_TEX)) {
-                            if (pass) { dep[i] = z; col[i] = (uint32_t)q3.z; }
+                            if (pass) {
+                                if (!(flags & TF_NODW)) dep[i] = z;
+                                if (flags & TF_BLENDSOLID) {
+                                    const uint32_t c8 = (uint32_t)q3.z;
+                                    const float src[4] = {unorm8f(c8), unorm8f(c8 >> 8), unorm8f(c8 >> 16), unorm8f(c8 >> 24)};
+                                    col[i] = blend_store(col[i], src, bmode);
+                                } else {
+                                    col[i] = (uint32_t)q3.z;
+                                }
+                            }
                         } else {
                             // every lane evaluates (u,v) so quad differences exist for helper pixels too
                             const TriX& Xt = s_tx[TEX ? t : 0];
@@ -426,15 +453,13 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
                             const float dvdx = __shfl(v, (int)(lane | 1)) - __shfl(v, (int)(lane & ~1u));
                             const float dudy = __shfl(u, (int)(lane | 8)) - __shfl(u, (int)(lane & ~8u));
                             const float dvdy = __shfl(v, (int)(lane | 8)) - __shfl(v, (int)(lane & ~8u));
-                            const TexRef tr = {Xt.tex, Xt.tw, Xt.th};
-                            const float fw = (float)tr.tw, fh = (float)tr.th;
-                            const bool linear = (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) &&
-                                                (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
+                            const TexRef tr = {Xt.tex, Xt.tw, Xt.th, Xt.tlevels};
+                            const int flt = filter_select(dudx, dvdx, dudy, dvdy, tr.tw, tr.th, tr.levels);
                             if (pass) {
-                                dep[i] = z;
+                                if (!(flags & TF_NODW)) dep[i] = z;
                                 float src[4];
-                                sample_texture(tr, u, v, linear, src);
-                                col[i] = blend_store(col[i], src, (flags & TF_BLEND) != 0);
+                                sample_texture(tr, u, v, flt, src);
+                                col[i] = blend_store(col[i], src, bmode);
                             }
                         }
                     }

@@ -129,10 +129,10 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
     uv_at(px, py ^ 1, uw, vw);
     const float dudx = (px & 1) ? u - uh : uh - u, dvdx = (px & 1) ? v - vh : vh - v;
     const float dudy = (py & 1) ? u - uw : uw - u, dvdy = (py & 1) ? v - vw : vw - v;
-    const TexRef tr = {mat.tex, mat.tw, mat.th};
+    const TexRef tr = {mat.tex, mat.tw, mat.th, mat.tlevels};
     float src[4];
-    sample_texture(tr, u, v, filter_is_linear(dudx, dvdx, dudy, dvdy, mat.tw, mat.th), src);
-    return blend_store(0u, src, false);  // opaque texture: a == 1 exactly, so the blend is a replace
+    sample_texture(tr, u, v, filter_select(dudx, dvdx, dudy, dvdy, mat.tw, mat.th, mat.tlevels), src);
+    return blend_store(0u, src, 0u);  // order-free: blending is off, or the texture is opaque (a == 1 exactly) and the blend a replace
 }
 
 // waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
@@ -347,10 +347,15 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
             // the last word of the record: the source colour of a solid triangle (top byte 0xFF) or a material id
             const uint32_t payload = P.fb.rec_a[r].q1.w;
-            if (TEX && (payload >> 24) != 0xFFu) {
-                const RecA a = load_rec(P.fb, r);
-                const RecB b = P.fb.rec_b[r];
-                col = shade_textured(a, b, P.mats[a.mat], (int32_t)x, (int32_t)y);
+            if ((payload >> 24) != 0xFFu) {  // needs its material: in this kernel (order-free triangles only) a textured one
+                const DMat mat = P.mats[payload & 0xFFFFFFu];
+                if (TEX && mat.shader == MTR_SH_TEXTURED) {
+                    const RecA a = load_rec(P.fb, r);
+                    const RecB b = P.fb.rec_b[r];
+                    col = shade_textured(a, b, mat, (int32_t)x, (int32_t)y);
+                } else {
+                    col = mat.rgba8;
+                }
             } else {
                 col = payload;
             }

@@ -176,8 +176,9 @@ struct Exchange {
 struct mtr_texture {
     mtr_device* dev;
     uint32_t w, h, fmt;
+    uint32_t levels = 1;  // mip levels in d_rgba, level 0 first
     uint8_t* d_rgba;
-    bool opaque;  // every decoded texel has alpha == 255: sampling it yields a == 1 exactly
+    bool opaque;  // every decoded texel (of every level) has alpha == 255: sampling it yields a == 1 exactly
 };
 
 struct mtr_model {
@@ -206,6 +207,7 @@ struct mtr_model {
     std::vector<int32_t> prim_to_texture;
     std::vector<mtr_texture*> textures;
     std::vector<uint32_t> debug_rgba8;
+    std::vector<mtr_prim_state> states;  // material state per primitive, empty: the reference's pipeline state
     std::vector<DChunk> chunks;
     uint64_t ntris_visible = 0;
     bool chunks_dirty = true;
@@ -324,6 +326,7 @@ uint32_t elem_bytes(uint8_t fmt, uint8_t cnt) {
     case MTR_IEF_F16: return cnt == 2 ? 4 : 0;
     case MTR_IEF_F32: return cnt == 3 ? 12 : 0;
     case MTR_IEF_U8NL: return cnt == 3 ? 4 : 0;
+    case MTR_IEF_SCMP3N: return 4;  // only reached with MTR_ELEM_DECODE_SCMP3N
     default: return 0;
     }
 }
@@ -546,6 +549,15 @@ void decode_pos_host(uint32_t fmt, uint32_t cnt, const uint8_t* p, float (&o)[3]
     case MTR_IEF_F32:
         memcpy(&o[0], p, 4); memcpy(&o[1], p + 4, 4); memcpy(&o[2], p + 8, 4);
         break;
+    case MTR_IEF_SCMP3N: {
+        uint32_t w;
+        memcpy(&w, p, 4);
+        for (int k = 0; k < 3; k++) {
+            const float f = (float)((int32_t)((w >> (10 * k)) << 22) >> 22) / 511.0f;
+            o[k] = f < -1.0f ? -1.0f : f;
+        }
+        break;
+    }
     default: break;
     }
 }
@@ -797,21 +809,28 @@ int32_t mtr_device_set_profiling(mtr_device* d, int32_t enable) {
 // ---------------------------------------------------------------------------------------------
 // Texture::new
 // ---------------------------------------------------------------------------------------------
-int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, const void* data, size_t len,
-                           mtr_texture** out) {
+int32_t mtr_texture_create_mips(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, uint32_t levels, const void* data, size_t len,
+                                mtr_texture** out) {
     if (!d || !out) return MTR_E_INVALID;
     *out = nullptr;
     if (!data || w == 0 || h == 0 || w > 16384 || h > 16384) return fail(d, MTR_E_INVALID, "bad texture size/data");
+    if (levels == 0 || levels > 15 || (levels > 1 && (w >> (levels - 1)) == 0 && (h >> (levels - 1)) == 0))
+        return fail(d, MTR_E_INVALID, "more mip levels than the texture size allows");
     if (fmt != MTR_TEX_RGBA8 && fmt != MTR_TEX_BC1 && fmt != MTR_TEX_BC7 && fmt != MTR_TEX_BC7_ALT)
         return fail(d, MTR_E_UNSUPPORTED, "unhandled texture format " + std::to_string(fmt));  // src/rtexture.rs:159
-    const size_t bw = (w + 3) / 4, bh = (h + 3) / 4;
-    const size_t need = fmt == MTR_TEX_RGBA8 ? (size_t)w * h * 4 : bw * bh * (fmt == MTR_TEX_BC1 ? 8 : 16);
+    // level l: max(1, w >> l) x max(1, h >> l), stored level after level in both the source and the decoded image
+    size_t need = 0, texels = 0;
+    for (uint32_t l = 0; l < levels; l++) {
+        const size_t lw = std::max(1u, w >> l), lh = std::max(1u, h >> l);
+        need += fmt == MTR_TEX_RGBA8 ? lw * lh * 4 : ((lw + 3) / 4) * ((lh + 3) / 4) * (fmt == MTR_TEX_BC1 ? 8 : 16);
+        texels += lw * lh;
+    }
     if (len < need) return fail(d, MTR_E_INVALID, "texture data too short");
     int32_t rc = set_device(d);
     if (rc) return rc;
     auto t = std::make_unique<mtr_texture>();
-    t->dev = d; t->w = w; t->h = h; t->fmt = fmt; t->d_rgba = nullptr;
-    rc = dev_alloc(d, &t->d_rgba, (size_t)w * h * 4);
+    t->dev = d; t->w = w; t->h = h; t->fmt = fmt; t->levels = levels; t->d_rgba = nullptr;
+    rc = dev_alloc(d, &t->d_rgba, texels * 4);
     if (rc) return rc;
     if (fmt == MTR_TEX_RGBA8) {
         HIPCHK(d, hipMemcpyAsync(t->d_rgba, data, need, hipMemcpyHostToDevice, d->stream));
@@ -821,8 +840,14 @@ int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, 
         rc = dev_alloc(d, &d_blocks, need);
         if (rc) { (void)hipFree(t->d_rgba); return rc; }
         HIPCHK(d, hipMemcpyAsync(d_blocks, data, need, hipMemcpyHostToDevice, d->stream));
-        if (fmt == MTR_TEX_BC1) mtr_launch_bc1_decode(d_blocks, t->d_rgba, w, h, d->stream);
-        else mtr_launch_bc7_decode(d_blocks, t->d_rgba, w, h, d->stream);
+        size_t src_off = 0, dst_off = 0;
+        for (uint32_t l = 0; l < levels; l++) {
+            const uint32_t lw = std::max(1u, w >> l), lh = std::max(1u, h >> l);
+            if (fmt == MTR_TEX_BC1) mtr_launch_bc1_decode(d_blocks + src_off, t->d_rgba + dst_off, lw, lh, d->stream);
+            else mtr_launch_bc7_decode(d_blocks + src_off, t->d_rgba + dst_off, lw, lh, d->stream);
+            src_off += (size_t)((lw + 3) / 4) * ((lh + 3) / 4) * (fmt == MTR_TEX_BC1 ? 8 : 16);
+            dst_off += (size_t)lw * lh * 4;
+        }
         HIPCHK(d, hipGetLastError());
         HIPCHK(d, hipStreamSynchronize(d->stream));
         (void)hipFree(d_blocks);
@@ -832,7 +857,7 @@ int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, 
         uint32_t h_min = 255;
         if ((rc = dev_alloc(d, &d_min, 1))) return rc;
         HIPCHK(d, hipMemcpyAsync(d_min, &h_min, 4, hipMemcpyHostToDevice, d->stream));
-        mtr_launch_alpha_min(t->d_rgba, (size_t)w * h, d_min, d->stream);
+        mtr_launch_alpha_min(t->d_rgba, texels, d_min, d->stream);
         HIPCHK(d, hipGetLastError());
         HIPCHK(d, hipMemcpyAsync(&h_min, d_min, 4, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
@@ -841,6 +866,10 @@ int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, 
     }
     *out = t.release();
     return MTR_OK;
+}
+
+int32_t mtr_texture_create(mtr_device* d, uint32_t w, uint32_t h, uint32_t fmt, const void* data, size_t len, mtr_texture** out) {
+    return mtr_texture_create_mips(d, w, h, fmt, 1, data, len, out);
 }
 
 void mtr_texture_destroy(mtr_texture* t) {
@@ -904,7 +933,7 @@ int32_t mtr_model_create(mtr_device* d, const void* vertex_buf, size_t vertex_le
         uint32_t align_or = pr.vertex_base | pr.stride;
         for (uint32_t i = 0; i < l.num_elements; i++) {
             const mtr_element& e = l.elements[i];
-            if (e.format == MTR_IEF_SCMP3N) continue;  // src/rshader2.rs:509-512
+            if (e.format == MTR_IEF_SCMP3N && !(e.flags & MTR_ELEM_DECODE_SCMP3N)) continue;  // src/rshader2.rs:509-512
             if (e.semantic == MTR_SEM_POSITION || e.semantic == MTR_SEM_TEXCOORD) {
                 uint32_t nb = elem_bytes(e.format, e.count);
                 if (nb == 0)  // todo!() arms of src/rshader2.rs:516-564 and integer formats
@@ -991,6 +1020,29 @@ void mtr_model_destroy(mtr_model* m) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
+}
+
+int32_t mtr_model_set_prim_states(mtr_model* m, const mtr_prim_state* states, size_t nprims) {
+    if (!m) return MTR_E_INVALID;
+    mtr_device* d = m->dev;
+    if (states && nprims != m->prims.size()) return fail(d, MTR_E_INVALID, "one state per primitive");
+    for (size_t p = 0; states && p < nprims; p++)
+        if (states[p].blend > MTR_BLEND_ADD || states[p].cull > MTR_CULL_FRONT) return fail(d, MTR_E_INVALID, "unknown blend / cull mode");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
+    if (states) m->states.assign(states, states + nprims); else m->states.clear();
+    bool changed = false;
+    for (size_t p = 0; p < m->prims.size(); p++) {
+        const uint32_t cull = states ? states[p].cull : (uint32_t)MTR_CULL_BACK;
+        changed = changed || m->prims[p].cull != cull;
+        m->prims[p].cull = cull;
+    }
+    if (changed) {  // the cull mode lives in the device copy of the primitive table: frames in flight may be reading it
+        if ((rc = drain_all(d))) return rc;
+        HIPCHK(d, hipMemcpy(m->d_prims, m->prims.data(), m->prims.size() * sizeof(DPrim), hipMemcpyHostToDevice));
+    }
+    return MTR_OK;
 }
 
 int32_t mtr_model_set_parts_disp(mtr_model* m, const uint8_t* parts_disp, size_t n) {
@@ -1418,19 +1470,27 @@ static int32_t run_frame(mtr_frame* f) {
                 DMat dm{};
                 int32_t tex = m->prim_to_texture[p];
                 if (tex >= 0 && !dr.tex_override.empty() && dr.tex_override[r] >= 0) tex = dr.tex_override[r];
-                dm.blend = dr.blend ? 1 : 0;
+                dm.blend = dr.blend ? MTR_DB_ALPHA : MTR_DB_OFF;
+                dm.dstate = 3u;  // depth write | depth test << 1
+                dm.tlevels = 1;
+                if (!m->states.empty() && dr.shader_override != MTR_SH_CONST) {  // material state (row f-4)
+                    const mtr_prim_state& st = m->states[p];
+                    dm.blend = st.blend == MTR_BLEND_OFF ? MTR_DB_OFF : (st.blend == MTR_BLEND_ADD ? MTR_DB_ADD : MTR_DB_ALPHA);
+                    dm.dstate = (st.depth_write ? 1u : 0u) | (st.depth_test ? 2u : 0u);
+                }
+                // order-dependent: an additive blend, or a depth state in which a fragment's fate depends on what came before
+                bool order_dep = dm.blend == MTR_DB_ADD || dm.dstate != 3u;
                 if (dr.shader_override == MTR_SH_CONST) {
                     dm.shader = MTR_SH_CONST; dm.rgba8 = dr.const_rgba8;
                 } else if (tex >= 0 && m->prims[p].has_uv) {  // src/model.rs:212-216
                     dm.shader = MTR_SH_TEXTURED;
-                    if (!m->textures[(size_t)tex]->opaque) {
-                        f->all_opaque = false;
-                        dm.translucent = dm.blend;
-                    }
-                    dm.tex = m->textures[(size_t)tex]->d_rgba; dm.tw = m->textures[(size_t)tex]->w; dm.th = m->textures[(size_t)tex]->h;
+                    const mtr_texture* t = m->textures[(size_t)tex];
+                    if (!t->opaque && dm.blend == MTR_DB_ALPHA) order_dep = true;  // a texel with alpha < 255 really blends
+                    dm.tex = t->d_rgba; dm.tw = t->w; dm.th = t->h; dm.tlevels = t->levels;
                 } else {
                     dm.shader = MTR_SH_DEBUG; dm.rgba8 = m->debug_rgba8[p];
                 }
+                if (order_dep) { dm.translucent = 1; f->all_opaque = false; }
                 mats.push_back(dm);
             }
     }

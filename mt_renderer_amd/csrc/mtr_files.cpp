@@ -342,15 +342,37 @@ int32_t mtr_rtexture_parse(const void* data, size_t len, mtr_rtexture_view* out)
     return MTR_OK;
 }
 
-int32_t mtr_texture_create_from_file(mtr_device* dev, const void* data, size_t len, mtr_texture** out) {
+int32_t mtr_texture_create_from_file_mips(mtr_device* dev, const void* data, size_t len, uint32_t max_levels, mtr_texture** out) {
     mtr_rtexture_view v;
     int32_t rc = mtr_rtexture_parse(data, len, &v);
     if (rc) return rc;
     if (v.format != MTR_TEX_RGBA8 && v.format != MTR_TEX_BC1 && v.format != MTR_TEX_BC7 && v.format != MTR_TEX_BC7_ALT)
         return ferr(MTR_E_UNSUPPORTED, "rTexture: unhandled texture format %u", v.format);
-    rc = mtr_texture_create(dev, v.width, v.height, v.format, v.data, v.data_len, out);
+    uint32_t levels = std::min(std::max(max_levels, 1u), std::min(v.level_count, 15u));
+    while (levels > 1 && (v.width >> (levels - 1)) == 0 && (v.height >> (levels - 1)) == 0) levels--;
+    if (levels <= 1) {
+        rc = mtr_texture_create(dev, v.width, v.height, v.format, v.data, v.data_len, out);
+        if (rc) ferr(rc, "rTexture: %s", mtr_last_error(dev));
+        return rc;
+    }
+    // gather the levels of array slice 0 through the offsets table (src/rtexture.rs:111-126): one u64 per image
+    const Span s{static_cast<const uint8_t*>(data), len};
+    std::vector<uint8_t> chain;
+    for (uint32_t l = 0; l < levels; l++) {
+        uint64_t off = 0;
+        if (!rd(s, sizeof(TextureHeader) + (uint64_t)l * 8, off)) return ferr(MTR_E_INVALID, "rTexture: truncated offset table");
+        const size_t lw = std::max(1u, v.width >> l), lh = std::max(1u, v.height >> l);
+        const size_t nb = v.format == MTR_TEX_RGBA8 ? lw * lh * 4 : ((lw + 3) / 4) * ((lh + 3) / 4) * (v.format == MTR_TEX_BC1 ? 8 : 16);
+        if (!s.at(off, nb, 1)) return ferr(MTR_E_INVALID, "rTexture: mip level %u lies outside the file", l);
+        chain.insert(chain.end(), s.p + off, s.p + off + nb);
+    }
+    rc = mtr_texture_create_mips(dev, v.width, v.height, v.format, levels, chain.data(), chain.size(), out);
     if (rc) ferr(rc, "rTexture: %s", mtr_last_error(dev));
     return rc;
+}
+
+int32_t mtr_texture_create_from_file(mtr_device* dev, const void* data, size_t len, mtr_texture** out) {
+    return mtr_texture_create_from_file_mips(dev, data, len, 1, out);
 }
 
 // -------------------------------------------------------------------------------------------- rShader2
@@ -534,6 +556,61 @@ int32_t mtr_rmaterial_find(const mtr_rmaterial* m, const char* name) {
     for (size_t i = 0; i < m->materials.size(); i++)
         if (m->materials[i].name_hash == hsh) return (int32_t)i;
     return -1;
+}
+
+// ------------------------------------------------------------------------------------------ material state by name
+int32_t mtr_state_from_names(const char* bs, const char* ds, const char* rs, mtr_prim_state* out) {
+    if (!out) return 0;
+    mtr_prim_state st = {MTR_BLEND_ALPHA, 1, 1, MTR_CULL_BACK};  // the reference's pipeline, src/model.rs:240-262
+    int32_t known = 0;
+    auto has = [](const std::string& n, const char* sub) { return n.find(sub) != std::string::npos; };
+    auto ends = [](const std::string& n, const char* suf) { const size_t k = strlen(suf); return n.size() >= k && n.compare(n.size() - k, k, suf) == 0; };
+    if (bs && *bs) {
+        const std::string n(bs);
+        if (has(n, "Add")) { st.blend = MTR_BLEND_ADD; known++; }
+        else if (has(n, "Blend") || has(n, "Alpha")) { st.blend = MTR_BLEND_ALPHA; known++; }
+        else if (n.compare(0, 2, "BS") == 0) { st.blend = MTR_BLEND_OFF; known++; }  // "BSSolid" and the other opaque states
+    }
+    if (ds && *ds) {
+        const std::string n(ds);
+        if (n.compare(0, 2, "DS") == 0) {
+            st.depth_test = has(n, "ZTest") ? 1 : 0;
+            st.depth_write = (has(n, "ZTestWrite") || has(n, "ZWrite")) ? 1 : 0;
+            known++;
+        }
+    }
+    if (rs && *rs) {
+        const std::string n(rs);
+        if (ends(n, "CN") || has(n, "CullNone") || has(n, "TwoSide")) { st.cull = MTR_CULL_NONE; known++; }
+        else if (ends(n, "CF") || has(n, "CullFront")) { st.cull = MTR_CULL_FRONT; known++; }
+        else if (n.compare(0, 2, "RS") == 0) { st.cull = MTR_CULL_BACK; known++; }
+    }
+    *out = st;
+    return known;
+}
+
+int32_t mtr_model_states_from_files(const mtr_rmodel_view* model, const mtr_rshader2* sh, const mtr_rmaterial* mat, mtr_prim_state* states,
+                                    size_t nstates) {
+    if (!model || !sh || !mat || !states) return ferr(MTR_E_INVALID, "states from files: null argument");
+    if (nstates != model->primitive_num) return ferr(MTR_E_INVALID, "states from files: one state per primitive");
+    for (size_t p = 0; p < nstates; p++) {
+        mtr_primitive pr;
+        memcpy(&pr, reinterpret_cast<const uint8_t*>(model->primitives) + p * sizeof pr, sizeof pr);
+        const uint32_t mno = mtr_primitive_field(&pr, MTR_PRIM_MATERIAL_NO);
+        mtr_state_from_names(nullptr, nullptr, nullptr, &states[p]);
+        if (mno >= model->material_num) return ferr(MTR_E_INVALID, "primitive %zu: material_no %u outside the name table", p, mno);
+        const int32_t mi = mtr_rmaterial_find(mat, reinterpret_cast<const char*>(model->material_names + (size_t)mno * 128));
+        if (mi < 0) continue;
+        const mtr_material_info& info = mat->materials[(size_t)mi];
+        const char* names[3] = {nullptr, nullptr, nullptr};
+        const uint32_t handles[3] = {info.bsstate, info.dsstate, info.rsstate};
+        for (int k = 0; k < 3; k++) {
+            const int32_t oi = mtr_rshader2_find(sh, handles[k]);
+            if (oi >= 0) names[k] = sh->objects[(size_t)oi].name.c_str();
+        }
+        mtr_state_from_names(names[0], names[1], names[2], &states[p]);
+    }
+    return MTR_OK;
 }
 
 // ------------------------------------------------------------------------------------------ rScheduler

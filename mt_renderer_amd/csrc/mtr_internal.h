@@ -31,7 +31,7 @@ struct DPrim {
     uint32_t joint_off, weight_off, skinnable;
     uint32_t aligned4;  // vertex_base, stride and every bound offset are multiples of 4
     uint32_t parts_no;
-    uint32_t pad;
+    uint32_t cull;      // MTR_CULL_*: 0 back (the reference, src/model.rs:252), 1 none, 2 front (material state, row f-4)
 };
 
 struct DChunk {
@@ -69,11 +69,15 @@ struct CompMat {
 struct DMat {            // one per (draw, [instance,] primitive)
     uint32_t shader;     // MTR_SH_*
     uint32_t rgba8;      // SH_DEBUG / SH_CONST: the quantised source colour
-    uint32_t blend;      // alpha blending on (src/model.rs:243-246) / off (debug overlay)
+    uint32_t blend;      // MTR_DB_*: alpha blending (src/model.rs:243-246), off (debug overlay), additive (material state)
     uint32_t tw, th;     // texture size
-    uint32_t translucent;  // order-dependent: blending on and the texture has a texel with alpha < 255
-    const uint8_t* tex;  // decoded RGBA8 texels
+    uint32_t translucent;  // order-dependent: the pixel depends on the order of the fragments (a blend that is not a
+                           // replace, depth write or depth test off): the ordered tile kernel's
+    const uint8_t* tex;  // decoded RGBA8 texels, mip levels one after the other
+    uint32_t tlevels;    // mip levels present (>= 1)
+    uint32_t dstate;     // bit0 depth write, bit1 depth test
 };
+enum { MTR_DB_OFF = 0, MTR_DB_ALPHA = 1, MTR_DB_ADD = 2 };  // DMat::blend (0 / 1 as before the material states)
 
 struct RecHdr {          // 8 B: bins covered, inclusive
     uint16_t bx0, by0, bx1, by1;
@@ -84,15 +88,16 @@ struct RecA {            // what coverage + depth need, in registers (see RecP f
     float z0, z1;
     float z2;
     uint32_t mat;
-    uint32_t pad0, pad1;  // pad0 = material rgba8 (debug / overlay colour), pad1 = shader | blend << 8 | translucent << 16
+    uint32_t pad0, pad1;  // pad0 = the colour of a solid triangle, pad1 = solid | blending << 8 | order-dependent << 16
 };
 // RecA as it lives in HBM: 32 B.  A surviving triangle is written once by k_geom and read once per bin it touches by
 // the tile kernel (692 k reads per headline frame), so the record is what both kernels' traffic is made of.
 //   q0 = { X0, Y0, dX1 | dY1 << 16, dX2 | dY2 << 16 }   vertex 1 / 2 relative to vertex 0, 16 bits each (24.8 fixed
 //        point: up to 128 px); a triangle with a longer edge stores dX1 = -32768 and its four coordinates in rec_l[]
 //   q1 = { z0, z1, z2, payload }
-//   payload: top byte 0xFF = the quantised source colour of a debug-id / overlay triangle (their alpha is 1); otherwise
-//            a textured triangle: material id (24 bits) | blend << 24 | translucent << 25
+//   payload: top byte 0xFF = the quantised source colour of a debug-id / overlay triangle in the default depth state
+//            (their alpha is 1: whatever the blend, the fragment replaces the pixel); otherwise a triangle whose
+//            shading needs its material: material id (24 bits) | blend != off << 24 | order-dependent << 25
 struct RecP {
     uint4 q0, q1;
 };
@@ -105,8 +110,8 @@ __device__ __forceinline__ bool rec_is_large(const RecA& a) {
 }
 __device__ __forceinline__ RecP rec_pack(const RecA& a, bool large) {
     RecP p;
-    const uint32_t shader = a.pad1 & 0xffu, blend = (a.pad1 >> 8) & 1u, transl = (a.pad1 >> 16) & 1u;
-    const uint32_t payload = shader == MTR_SH_TEXTURED ? ((a.mat & 0xFFFFFFu) | (blend << 24) | (transl << 25)) : (a.pad0 | 0xFF000000u);
+    const uint32_t solid = a.pad1 & 1u, blend = (a.pad1 >> 8) & 1u, transl = (a.pad1 >> 16) & 1u;
+    const uint32_t payload = solid ? (a.pad0 | 0xFF000000u) : ((a.mat & 0xFFFFFFu) | (blend << 24) | (transl << 25));
     const uint32_t d1 = large ? MTR_REC_LARGE_SENTINEL : (((uint32_t)(a.X1 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y1 - a.Y0) << 16));
     const uint32_t d2 = large ? 0u : (((uint32_t)(a.X2 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y2 - a.Y0) << 16));
     p.q0 = make_uint4((uint32_t)a.X0, (uint32_t)a.Y0, d1, d2);
@@ -125,8 +130,9 @@ __device__ __forceinline__ RecA rec_unpack(const RecP& p, const int4& l) {
     }
     a.z0 = __uint_as_float(p.q1.x); a.z1 = __uint_as_float(p.q1.y); a.z2 = __uint_as_float(p.q1.z);
     const uint32_t pl = p.q1.w;
-    if ((pl >> 24) == 0xFFu) { a.mat = 0; a.pad0 = pl; a.pad1 = MTR_SH_DEBUG | (1u << 8); }
-    else { a.mat = pl & 0xFFFFFFu; a.pad0 = 0; a.pad1 = MTR_SH_TEXTURED | (((pl >> 24) & 1u) << 8) | (((pl >> 25) & 1u) << 16); }
+    // pad1: bit0 solid (pad0 is the colour, no material needed), bit8 blending on, bit16 order-dependent
+    if ((pl >> 24) == 0xFFu) { a.mat = 0; a.pad0 = pl; a.pad1 = 1u; }
+    else { a.mat = pl & 0xFFFFFFu; a.pad0 = 0; a.pad1 = (((pl >> 24) & 1u) << 8) | (((pl >> 25) & 1u) << 16); }
     return a;
 }
 

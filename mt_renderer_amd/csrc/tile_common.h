@@ -56,17 +56,24 @@ __device__ __forceinline__ int32_t clamp_texel(float f, uint32_t n) {
 struct TexRef {
     const uint8_t* tex;
     uint32_t tw, th;
+    uint32_t levels;  // mip levels present (the reference uploads one, src/texture.rs:21; more: row f-4)
 };
 __device__ __forceinline__ void texel_f(const TexRef& m, int32_t x, int32_t y, float (&o)[4]) {
     uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[(size_t)y * m.tw + (size_t)x];
     o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
 }
 
-// textureSample: clamp-to-edge, mag linear / min nearest, one level (src/texture.rs:21,33-42).
-__device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v, bool linear, float (&o)[4]) {
+// textureSample: clamp-to-edge, mag linear / min nearest (src/texture.rs:33-42).  flt < 0: linear on level 0
+// (magnification); flt >= 0: the nearest texel of mip level flt (level 0 always when the texture has one level).
+__device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v, int flt, float (&o)[4]) {
     const float fw = (float)m.tw, fh = (float)m.th;
-    if (!linear) {
-        texel_f(m, clamp_texel(floorf(u * fw), m.tw), clamp_texel(floorf(v * fh), m.th), o);
+    if (flt >= 0) {
+        uint32_t lw = m.tw, lh = m.th;
+        size_t off = 0;
+        for (int l = 0; l < flt; l++) { off += (size_t)lw * lh; lw = lw > 1u ? lw >> 1 : 1u; lh = lh > 1u ? lh >> 1 : 1u; }
+        const int32_t x = clamp_texel(floorf(u * (float)lw), lw), y = clamp_texel(floorf(v * (float)lh), lh);
+        const uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[off + (size_t)y * lw + (size_t)x];
+        o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
         return;
     }
     float x = u * fw - 0.5f, y = v * fh - 0.5f;
@@ -84,15 +91,32 @@ __device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v
     }
 }
 
-__device__ __forceinline__ bool filter_is_linear(float dudx, float dvdx, float dudy, float dvdy, uint32_t tw, uint32_t th) {
+// SPEC.md section 7: -1 = linear (every derivative product <= 1: magnification), else the mip level of a nearest
+// sample: level l while m > 2^(l - 1/2), i.e. m * m > 2^(2l - 1), m = the largest product (NaN: level 0)
+__device__ __forceinline__ int filter_select(float dudx, float dvdx, float dudy, float dvdy, uint32_t tw, uint32_t th, uint32_t levels) {
     const float fw = (float)tw, fh = (float)th;
-    return (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) && (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
+    const float a = fabsf(dudx) * fw, b = fabsf(dvdx) * fh, c = fabsf(dudy) * fw, d = fabsf(dvdy) * fh;
+    if ((a <= 1.0f) && (b <= 1.0f) && (c <= 1.0f) && (d <= 1.0f)) return -1;
+    int level = 0;
+    if (levels > 1u) {
+        const float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
+        const float m2 = m * m;
+        float thr = 2.0f;
+        while ((uint32_t)level + 1u < levels && m2 > thr) { level++; thr *= 4.0f; }
+    }
+    return level;
 }
 
-// SrcAlpha / OneMinusSrcAlpha colour, One / Zero alpha (src/model.rs:243-246), UNORM8 store
-__device__ __forceinline__ uint32_t blend_store(uint32_t dst, const float (&src)[4], bool blend) {
+// blend 1: SrcAlpha / OneMinusSrcAlpha colour, One / Zero alpha (src/model.rs:243-246); 2: additive, SrcAlpha / One
+// (material state, SPEC.md section 10); 0: replace.  UNORM8 store.
+__device__ __forceinline__ uint32_t blend_store(uint32_t dst, const float (&src)[4], uint32_t blend) {
     uint32_t out = 0;
-    if (blend) {
+    if (blend == 2u) {
+        const float a = src[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) out |= quant8(fmaf(src[c], a, unorm8f(dst >> (8 * c)))) << (8 * c);
+        out |= quant8(src[3]) << 24;
+    } else if (blend) {
         const float a = src[3], ia = 1.0f - a;
 #pragma unroll
         for (int c = 0; c < 3; c++) {

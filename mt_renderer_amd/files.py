@@ -18,7 +18,8 @@ from .api import MtrError, lib
 
 EXPORTED_SYMBOLS = [
     "mtr_files_last_error", "mtr_file_struct_size", "mtr_rmodel_parse", "mtr_primitive_field", "mtr_rmodel_boundary_joint",
-    "mtr_rmodel_joint", "mtr_rtexture_parse", "mtr_texture_create_from_file", "mtr_rshader2_parse", "mtr_rshader2_destroy",
+    "mtr_rmodel_joint", "mtr_rtexture_parse", "mtr_texture_create_from_file", "mtr_texture_create_from_file_mips",
+    "mtr_state_from_names", "mtr_model_states_from_files", "mtr_rshader2_parse", "mtr_rshader2_destroy",
     "mtr_rshader2_num_objects", "mtr_rshader2_object", "mtr_rshader2_find", "mtr_rshader2_input_layout",
     "mtr_rmaterial_parse", "mtr_rmaterial_destroy", "mtr_rmaterial_num_textures", "mtr_rmaterial_texture_path",
     "mtr_rmaterial_num_materials", "mtr_rmaterial_info", "mtr_rmaterial_find", "mtr_rscheduler_parse",
@@ -97,6 +98,9 @@ lib.mtr_rmodel_joint.argtypes = [C.POINTER(_RModelView), C.c_uint32, C.POINTER(C
                                  C.POINTER(C.c_uint32), C.POINTER(C.c_float)]
 lib.mtr_rtexture_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_RTextureView)]
 lib.mtr_texture_create_from_file.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+lib.mtr_texture_create_from_file_mips.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.mtr_state_from_names.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
+lib.mtr_model_states_from_files.argtypes = [C.POINTER(_RModelView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 lib.mtr_rshader2_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
 lib.mtr_rshader2_destroy.restype = None
 lib.mtr_rshader2_destroy.argtypes = [C.c_void_p]
@@ -217,10 +221,11 @@ class TextureFile:
     def data(self) -> bytes:
         return bytes((C.c_uint8 * self.v.data_len).from_address(self.v.data)) if self.v.data_len else b""
 
-    def upload(self, dev: api.Device) -> api.Texture:
-        """Texture::new (src/texture.rs:11-30)."""
+    def upload(self, dev: api.Device, max_levels: int = 1) -> api.Texture:
+        """Texture::new (src/texture.rs:11-30): level 0 only, like the reference; max_levels > 1 also uploads the file's
+        mip chain (row f-4)."""
         h = C.c_void_p()
-        _check(lib.mtr_texture_create_from_file(dev._h, self._b, self._len, C.byref(h)))
+        _check(lib.mtr_texture_create_from_file_mips(dev._h, self._b, self._len, max_levels, C.byref(h)))
         t = api.Texture(dev, h)
         t.width, t.height = self.v.width, self.v.height
         return t
@@ -362,6 +367,22 @@ class ArchiveFile:
         n = C.c_size_t()
         _check(lib.mtr_rarchive_extract(C.byref(self.v), i, out, ri.size_uncompressed, C.byref(n)))
         return bytes(out[:n.value])
+
+
+def state_from_names(bs: Optional[str], ds: Optional[str], rs: Optional[str]):
+    """(blend, depth_write, depth_test, cull), and how many of the names an explicit rule recognised (include/mtr_files.h)"""
+    st = (C.c_uint8 * 4)()
+    enc = lambda n: None if n is None else n.encode()
+    known = lib.mtr_state_from_names(enc(bs), enc(ds), enc(rs), st)
+    return tuple(st), known
+
+
+def states_from_files(model: "ModelFile", shader2: "Shader2File", material: "MaterialFile") -> np.ndarray:
+    """uint8 [primitives, 4] for Model.set_prim_states: each primitive's material -> its state objects' names -> states"""
+    n = model.v.primitive_num
+    out = np.zeros((n, 4), dtype=np.uint8)
+    _check(lib.mtr_model_states_from_files(C.byref(model.v), shader2.h, material.h, out.ctypes.data_as(C.c_void_p), n))
+    return out
 
 
 def model_from_files(dev: api.Device, model: ModelFile, shader2: Shader2File, material: Optional[MaterialFile],

@@ -35,6 +35,7 @@ class TextureData:
     height: int
     fmt: int
     data: bytes
+    levels: int = 1  # mip levels in `data`, level 0 first (the reference uploads one: src/texture.rs:21)
 
 
 @dataclasses.dataclass
@@ -50,6 +51,9 @@ class ModelData:
     prim_debug_id: np.ndarray  # uint32 [nprims]
     parts_disp: np.ndarray  # uint8, default all-true with len = nprims (src/model.rs:270)
     textures: List[TextureData] = dataclasses.field(default_factory=list)
+    # material state per primitive, uint8 [nprims, 4] = blend (0 alpha, 1 off, 2 additive), depth write, depth test,
+    # cull (0 back, 1 none, 2 front); None = the reference's pipeline state (src/model.rs:240-262).  SPEC 10.
+    prim_states: Optional[np.ndarray] = None
 
     @property
     def nprims(self) -> int:

@@ -289,8 +289,14 @@ static uint32_t elem_bytes(uint8_t fmt, uint8_t cnt) {
     case ORC_IEF_F16: return cnt == 2 ? 4 : 0;                     /* Float16x2 */
     case ORC_IEF_F32: return cnt == 3 ? 12 : 0;                    /* Float32x3 */
     case ORC_IEF_U8NL: return cnt == 3 ? 4 : 0;                    /* Unorm8x4 */
+    case ORC_IEF_SCMP3N: return 4;                                 /* 10:10:10 signed normalised (build extension, SPEC 2) */
     default: return 0;
     }
+}
+static float snorm10f(uint32_t bits10) {
+    int32_t v = (int32_t)(bits10 << 22) >> 22;
+    float f = (float)v / 511.0f;
+    return f < -1.0f ? -1.0f : f;
 }
 static void elem_decode(uint8_t fmt, uint8_t cnt, const uint8_t *p, float out[4]) {
     out[0] = out[1] = out[2] = 0.0f;
@@ -315,6 +321,13 @@ static void elem_decode(uint8_t fmt, uint8_t cnt, const uint8_t *p, float out[4]
     case ORC_IEF_F32:
         for (uint32_t i = 0; i < 3; i++) memcpy(&out[i], p + 4 * i, 4);
         break;
+    case ORC_IEF_SCMP3N: {
+        uint32_t w = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        out[0] = snorm10f(w & 0x3ff);
+        out[1] = snorm10f((w >> 10) & 0x3ff);
+        out[2] = snorm10f((w >> 20) & 0x3ff);
+        break;
+    }
     default: break;
     }
 }
@@ -329,7 +342,8 @@ static int layout_resolve(const orc_layout *l, layout_info *li) {
     if (l->num > 8) return ORC_E_INVALID;
     for (uint32_t i = 0; i < l->num; i++) {
         const orc_element *e = &l->el[i];
-        if (e->format == ORC_IEF_SCMP3N) continue; /* src/rshader2.rs:509-512 */
+        /* src/rshader2.rs:509-512 skips these; pad0 bit 0 (ORC_ELEM_DECODE_SCMP3N) opts into this build's decode */
+        if (e->format == ORC_IEF_SCMP3N && !(e->pad0 & 1)) continue;
         switch (e->semantic) {
         case ORC_SEM_POSITION:
         case ORC_SEM_TEXCOORD:
@@ -560,17 +574,31 @@ static cvert clip_lerp(cvert in, cvert out) { /* in.z >= 0 > out.z */
     return r;
 }
 
-static int setup_tri(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, tri_setup *s) {
+enum { CULL_BACK = 0, CULL_NONE = 1, CULL_FRONT = 2 };
+
+static int setup_tri(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int cull, tri_setup *s) {
     pvert p[3] = {project(a, W, H), project(b, W, H), project(c, W, H)};
     s->valid = 0;
     if (!(p[0].ok && p[1].ok && p[2].ok)) return 0;
+    int64_t A2 = (int64_t)(p[2].X - p[0].X) * (int64_t)(p[1].Y - p[0].Y) -
+                 (int64_t)(p[1].X - p[0].X) * (int64_t)(p[2].Y - p[0].Y);
+    /* cull_mode Back, front_face Ccw: src/model.rs:252.  Material state (SPEC 10): a back face that is kept is set
+     * up with its second and third vertex exchanged, i.e. as the front face it is when seen from behind. */
+    if (cull == CULL_BACK) {
+        if (A2 <= 0) return 0;
+    } else {
+        if (A2 == 0 || (cull == CULL_FRONT && A2 > 0)) return 0;
+        if (A2 < 0) {
+            pvert t = p[1];
+            p[1] = p[2];
+            p[2] = t;
+            A2 = -A2;
+        }
+    }
     for (int i = 0; i < 3; i++) {
         s->X[i] = p[i].X;
         s->Y[i] = p[i].Y;
     }
-    int64_t A2 = (int64_t)(s->X[2] - s->X[0]) * (int64_t)(s->Y[1] - s->Y[0]) -
-                 (int64_t)(s->X[1] - s->X[0]) * (int64_t)(s->Y[2] - s->Y[0]);
-    if (A2 <= 0) return 0; /* cull_mode Back, front_face Ccw: src/model.rs:252 */
     s->A2 = A2;
     s->rcpA = 1.0f / (float)A2;
     s->z0 = p[0].z;
@@ -605,7 +633,7 @@ static int setup_tri(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, tri_setu
 }
 
 /* assembles up to two screen triangles from one clip-space triangle; returns the count */
-static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, tri_setup out[2]) {
+static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int cull, tri_setup out[2]) {
     out[0].valid = out[1].valid = 0;
     /* trivial frustum reject; the WebGPU clip volume is -w<=x<=w, -w<=y<=w, 0<=z<=w */
     if (a.x < -a.w && b.x < -b.w && c.x < -c.w) return 0;
@@ -615,7 +643,7 @@ static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, tri
     if (a.z < 0.0f && b.z < 0.0f && c.z < 0.0f) return 0;
     if (a.z > a.w && b.z > b.w && c.z > c.w) return 0;
     if (!(a.z < 0.0f || b.z < 0.0f || c.z < 0.0f)) {
-        setup_tri(a, b, c, W, H, &out[0]);
+        setup_tri(a, b, c, W, H, cull, &out[0]);
         return 1;
     }
     /* near-plane clip (z >= 0), Sutherland-Hodgman over the cycle a,b,c; intersections are always
@@ -629,8 +657,8 @@ static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, tri
         if (pin != qin) poly[n++] = pin ? clip_lerp(p, q) : clip_lerp(q, p);
     }
     if (n < 3) return 0;
-    setup_tri(poly[0], poly[1], poly[2], W, H, &out[0]);
-    if (n == 4) setup_tri(poly[0], poly[2], poly[3], W, H, &out[1]);
+    setup_tri(poly[0], poly[1], poly[2], W, H, cull, &out[0]);
+    if (n == 4) setup_tri(poly[0], poly[2], poly[3], W, H, cull, &out[1]);
     return n - 2;
 }
 
@@ -645,9 +673,14 @@ static const uint8_t DEBUG_PALETTE[20][3] = {
     {161, 71, 103}, {53, 133, 98},  {225, 131, 152}, {111, 111, 40}, {162, 99, 55},
 };
 
+enum { BLEND_ALPHA = 0, BLEND_OFF = 1, BLEND_ADD = 2 };
+
 typedef struct {
     int shader;
-    int blend;
+    int blend;       /* BLEND_*: ALPHA is the reference's pipeline (src/model.rs:243-246) */
+    int depth_write; /* src/model.rs:257 */
+    int depth_test;  /* LessEqual (src/model.rs:258) or always */
+    int cull;        /* CULL_* */
     float const_rgba[4];
     const orc_texture *tex;
 } fs_state;
@@ -681,6 +714,18 @@ static void texel_f(const orc_texture *t, int32_t x, int32_t y, float out[4]) {
     const uint8_t *p = t->rgba + ((size_t)y * t->w + (size_t)x) * 4;
     for (int c = 0; c < 4; c++) out[c] = unorm8f(p[c]);
 }
+/* level l of a mip chain: max(1, w >> l) x max(1, h >> l) texels, stored right after level l - 1 */
+static void texel_level_f(const orc_texture *t, uint32_t level, int32_t x, int32_t y, float out[4]) {
+    size_t off = 0;
+    uint32_t lw = t->w, lh = t->h;
+    for (uint32_t l = 0; l < level; l++) {
+        off += (size_t)lw * lh * 4;
+        lw = lw > 1 ? lw >> 1 : 1;
+        lh = lh > 1 ? lh >> 1 : 1;
+    }
+    const uint8_t *p = t->rgba + off + ((size_t)y * lw + (size_t)x) * 4;
+    for (int c = 0; c < 4; c++) out[c] = unorm8f(p[c]);
+}
 
 /* textureSample with the reference's sampler (src/texture.rs:33-42): clamp-to-edge, mag linear,
  * min nearest, one mip level (src/texture.rs:21).  SPEC.md "sampling". */
@@ -699,8 +744,25 @@ static void sample_texture(const orc_texture *t, const tri_setup *s, int32_t px,
     int linear = (fabsf(dudx) * fw <= 1.0f) && (fabsf(dvdx) * fh <= 1.0f) &&
                  (fabsf(dudy) * fw <= 1.0f) && (fabsf(dvdy) * fh <= 1.0f);
     if (!linear) {
-        int32_t tx = clamp_texel(floorf(u * fw), t->w), ty = clamp_texel(floorf(v * fh), t->h);
-        texel_f(t, tx, ty, out);
+        /* minification: nearest texel of the nearest mip level (src/texture.rs:39-40).  With m the largest of the four
+         * products above, level l is taken while m > 2^(l - 1/2), i.e. m*m > 2^(2l - 1); one level (the reference,
+         * src/texture.rs:21) never leaves level 0.  NaN compares false: level 0. */
+        uint32_t level = 0, nlev = t->levels ? t->levels : 1;
+        if (nlev > 1) {
+            float m = fmaxf(fmaxf(fabsf(dudx) * fw, fabsf(dvdx) * fh), fmaxf(fabsf(dudy) * fw, fabsf(dvdy) * fh));
+            float m2 = m * m, thr = 2.0f;
+            while (level + 1 < nlev && m2 > thr) {
+                level++;
+                thr *= 4.0f;
+            }
+        }
+        uint32_t lw = t->w, lh = t->h;
+        for (uint32_t l = 0; l < level; l++) {
+            lw = lw > 1 ? lw >> 1 : 1;
+            lh = lh > 1 ? lh >> 1 : 1;
+        }
+        int32_t tx = clamp_texel(floorf(u * (float)lw), lw), ty = clamp_texel(floorf(v * (float)lh), lh);
+        texel_level_f(t, level, tx, ty, out);
         return;
     }
     float x = u * fw - 0.5f, y = v * fh - 0.5f;
@@ -752,8 +814,8 @@ static uint64_t raster_tri(orc_frame *f, const tri_setup *s, const fs_state *fs,
             float z = fmaf(b2, s->dz2, fmaf(b1, s->dz1, s->z0));
             if (!(z >= 0.0f && z <= 1.0f)) continue; /* near/far clip, unclipped_depth off */
             size_t pi = (size_t)py * f->w + (size_t)px;
-            if (!(z <= f->depth[pi])) continue; /* LessEqual, src/model.rs:258 */
-            f->depth[pi] = z;                    /* depth_write_enabled, src/model.rs:257 */
+            if (fs->depth_test && !(z <= f->depth[pi])) continue; /* LessEqual, src/model.rs:258 */
+            if (fs->depth_write) f->depth[pi] = z;                /* depth_write_enabled, src/model.rs:257 */
             frags++;
             float src[4];
             if (fs->shader == SH_TEXTURED)
@@ -761,7 +823,7 @@ static uint64_t raster_tri(orc_frame *f, const tri_setup *s, const fs_state *fs,
             else
                 memcpy(src, fs->const_rgba, sizeof src);
             uint8_t *dst = f->color + pi * 4;
-            if (fs->blend) {
+            if (fs->blend == BLEND_ALPHA) {
                 /* SrcAlpha / OneMinusSrcAlpha colour, One / Zero alpha: src/model.rs:243-246 */
                 float a = src[3], ia = 1.0f - a;
                 for (int c = 0; c < 3; c++) {
@@ -769,6 +831,11 @@ static uint64_t raster_tri(orc_frame *f, const tri_setup *s, const fs_state *fs,
                     float t = d * ia;
                     dst[c] = quant8(fmaf(src[c], a, t));
                 }
+                dst[3] = quant8(src[3]);
+            } else if (fs->blend == BLEND_ADD) {
+                /* additive (material state, SPEC 10): SrcAlpha / One colour, One / Zero alpha */
+                float a = src[3];
+                for (int c = 0; c < 3; c++) dst[c] = quant8(fmaf(src[c], a, unorm8f(dst[c])));
                 dst[3] = quant8(src[3]);
             } else {
                 for (int c = 0; c < 4; c++) dst[c] = quant8(src[c]);
@@ -840,7 +907,7 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
         /* a vertex outside the bound slice (src/model.rs:337-342): triangle dropped (SPEC.md) */
         if (vi[0] >= vc->vnum || vi[1] >= vc->vnum || vi[2] >= vc->vnum) continue;
         cvert a = shade_vertex(vc, vi[0]), b = shade_vertex(vc, vi[1]), c = shade_vertex(vc, vi[2]);
-        clip_and_setup(a, b, c, f->w, f->h, &su[2 * i]);
+        clip_and_setup(a, b, c, f->w, f->h, fs->cull, &su[2 * i]);
         nsetup += (uint64_t)(su[2 * i].valid + su[2 * i + 1].valid);
     }
     f->tris_setup += nsetup;
@@ -927,7 +994,17 @@ int orc_draw(orc_frame *f, const orc_model *m, const float M[16], const float *p
         if (tex >= 0 && tex_override >= 0) tex = tex_override;
         fs_state fs;
         memset(&fs, 0, sizeof fs);
-        fs.blend = 1; /* src/model.rs:243-246 */
+        fs.blend = BLEND_ALPHA; /* src/model.rs:243-246 */
+        fs.depth_write = fs.depth_test = 1;
+        fs.cull = CULL_BACK;
+        if (m->prim_state) { /* material state per primitive (SPEC 10): blend, depth write, depth test, cull */
+            const uint8_t *st = m->prim_state + 4 * p;
+            if (st[0] > 2 || st[3] > 2) return ORC_E_INVALID;
+            fs.blend = st[0];
+            fs.depth_write = st[1] != 0;
+            fs.depth_test = st[2] != 0;
+            fs.cull = st[3];
+        }
         /* pipeline choice, src/model.rs:212-216: textured && attributes.len() != 1 */
         if (tex >= 0 && vc.li.has_uv) {
             fs.shader = SH_TEXTURED;
@@ -975,7 +1052,9 @@ int orc_draw_overlay_cubes(orc_frame *f, const float cam[16], const float *inst,
     fs_state fs;
     memset(&fs, 0, sizeof fs);
     fs.shader = SH_CONST;
-    fs.blend = 0; /* blend: None, src/debug_overlay.rs:174 */
+    fs.blend = BLEND_OFF; /* blend: None, src/debug_overlay.rs:174 */
+    fs.depth_write = fs.depth_test = 1;
+    fs.cull = CULL_BACK;
     fs.const_rgba[0] = 0.1f;
     fs.const_rgba[1] = 0.2f;
     fs.const_rgba[2] = 0.3f;

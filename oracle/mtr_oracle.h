@@ -53,7 +53,8 @@ typedef struct {
 
 typedef struct {
     uint32_t w, h;
-    const uint8_t *rgba; /* decoded RGBA8, row-major, w*h*4 bytes */
+    const uint8_t *rgba; /* decoded RGBA8, row-major, w*h*4 bytes; further mip levels follow, each max(1, w>>l) x max(1, h>>l) */
+    uint32_t levels;     /* mip levels present (0 and 1 both mean level 0 only: the reference, src/texture.rs:21) */
 } orc_texture;
 
 typedef struct {
@@ -70,6 +71,9 @@ typedef struct {
     size_t nparts;
     const orc_texture *textures;
     size_t ntextures;
+    /* material state per primitive, 4 bytes each {blend 0 alpha / 1 off / 2 additive, depth write, depth test, cull 0 back /
+     * 1 none / 2 front}, or NULL: the reference's pipeline state (src/model.rs:240-262).  Build extension, SPEC 10. */
+    const uint8_t *prim_state;
 } orc_model;
 
 typedef struct orc_frame orc_frame;

@@ -23,7 +23,7 @@ class _Layout(C.Structure):
 
 
 class _Texture(C.Structure):
-    _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("rgba", C.c_void_p)]
+    _fields_ = [("w", C.c_uint32), ("h", C.c_uint32), ("rgba", C.c_void_p), ("levels", C.c_uint32)]
 
 
 class _Model(C.Structure):
@@ -31,7 +31,7 @@ class _Model(C.Structure):
                 ("index_num", C.c_size_t), ("prims", C.c_void_p), ("nprims", C.c_size_t),
                 ("layouts", C.POINTER(_Layout)), ("prim_to_texture", C.c_void_p), ("prim_debug_id", C.c_void_p),
                 ("parts_disp", C.c_void_p), ("nparts", C.c_size_t), ("textures", C.POINTER(_Texture)),
-                ("ntextures", C.c_size_t)]
+                ("ntextures", C.c_size_t), ("prim_state", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:
@@ -113,6 +113,28 @@ def decode_texture(fmt: int, w: int, h: int, data: bytes) -> np.ndarray:
     return out
 
 
+def level_sizes(w: int, h: int, levels: int):
+    out = []
+    for _ in range(max(1, levels)):
+        out.append((w, h))
+        w, h = max(1, w >> 1), max(1, h >> 1)
+    return out
+
+
+def level_bytes(fmt: int, w: int, h: int) -> int:
+    return w * h * 4 if fmt == 7 else ((w + 3) // 4) * ((h + 3) // 4) * (8 if fmt == 19 else 16)
+
+
+def decode_texture_levels(fmt: int, w: int, h: int, data: bytes, levels: int = 1) -> np.ndarray:
+    """every mip level decoded to RGBA8, concatenated (level l is max(1, w >> l) x max(1, h >> l))"""
+    parts, off = [], 0
+    for lw, lh in level_sizes(w, h, levels):
+        n = level_bytes(fmt, lw, lh)
+        parts.append(decode_texture(fmt, lw, lh, data[off:off + n]).reshape(-1))
+        off += n
+    return np.concatenate(parts)
+
+
 def decode_bc7_blocks(blocks: np.ndarray) -> np.ndarray:
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1, 16)
     out = np.zeros((blocks.shape[0], 16, 4), dtype=np.uint8)
@@ -153,13 +175,14 @@ class OracleModel:
         lays = (_Layout * len(md.layouts))()
         for i, els in enumerate(md.layouts):
             lays[i].num = len(els)
-            for j, (sem, fmt, cnt, off) in enumerate(els[:8]):
-                lays[i].el[j].semantic, lays[i].el[j].format, lays[i].el[j].count, lays[i].el[j].offset = sem, fmt, cnt, off
+            for j, el in enumerate(els[:8]):  # (semantic, format, count, offset[, flags])
+                lays[i].el[j].semantic, lays[i].el[j].format, lays[i].el[j].count, lays[i].el[j].offset = el[:4]
+                lays[i].el[j].pad0 = el[4] if len(el) > 4 else 0
         texs = (_Texture * max(1, len(md.textures)))()
         for i, t in enumerate(md.textures):
-            dec = decode_texture(t.fmt, t.width, t.height, t.data)
+            dec = decode_texture_levels(t.fmt, t.width, t.height, t.data, getattr(t, "levels", 1))
             k.append(dec)
-            texs[i].w, texs[i].h, texs[i].rgba = t.width, t.height, dec.ctypes.data
+            texs[i].w, texs[i].h, texs[i].rgba, texs[i].levels = t.width, t.height, dec.ctypes.data, getattr(t, "levels", 1)
         k += [vb, ib, pr, p2t, did, pd, lays, texs]
         m = _Model()
         m.vertex_buf, m.vertex_len = vb.ctypes.data, vb.size
@@ -169,6 +192,12 @@ class OracleModel:
         m.prim_to_texture, m.prim_debug_id = p2t.ctypes.data, did.ctypes.data
         m.parts_disp, m.nparts = pd.ctypes.data, pd.size
         m.textures, m.ntextures = texs, len(md.textures)
+        st = getattr(md, "prim_states", None)
+        if st is not None:
+            st = np.ascontiguousarray(st, dtype=np.uint8).reshape(-1, 4)
+            assert st.shape[0] == pr.shape[0]
+            k.append(st)
+            m.prim_state = st.ctypes.data
         self.c = m
 
     def vertex_stage(self, prim: int, M: np.ndarray, palette: Optional[np.ndarray] = None):

@@ -50,8 +50,15 @@ def write_rtexture(width: int, height: int, fmt: int, data: bytes, prebias: int 
     n = array_count * level_count
     hdr = magic + struct.pack("<III", b4, b8, bc)
     off0 = 16 + 8 * n
-    offs = b"".join(struct.pack("<Q", off0 + i * 0) for i in range(n))  # only offsets[0] is read (src/rtexture.rs:126)
-    return hdr + offs + data
+    # the reference reads offsets[0] only (src/rtexture.rs:126); the other levels' offsets are what a real file carries
+    # (level l = max(1, w >> l) x max(1, h >> l) in the file's format), and what the mip-chain upload follows
+    offs, off = [], off0
+    for i in range(n):
+        l = i % max(1, level_count)
+        lw, lh = max(1, width >> l), max(1, height >> l)
+        offs.append(off)
+        off += lw * lh * 4 if fmt == 7 else ((lw + 3) // 4) * ((lh + 3) // 4) * (8 if fmt == 19 else 16)
+    return hdr + b"".join(struct.pack("<Q", o) for o in offs) + data
 
 
 # ------------------------------------------------------------------------------------------------ rShader2
@@ -175,6 +182,13 @@ def write_rmodel(md: scene.ModelData, prim_layout_handle: Sequence[int], materia
     return hdr + struct.pack("<I", np_) + bytes(body)
 
 
+STATE_NAMES = {  # (blend, depth_write, depth_test, cull) -> state object names of the synthetic shader package
+    "bs": {0: "BSBlendAlpha", 1: "BSSolid", 2: "BSAddAlpha"},
+    "ds": {(1, 1): "DSZTestWrite", (0, 1): "DSZTest", (1, 0): "DSZWrite", (0, 0): "DSNone"},
+    "rs": {0: "RSMesh", 1: "RSMeshCN", 2: "RSMeshCF"},
+}
+
+
 def files_from_model_data(md: scene.ModelData, texture_paths: Optional[Sequence[str]] = None):
     """ModelData -> (rmodel, rshader2, rmaterial, [rtexture...]) byte strings describing the same model the way
     real assets would: layouts become shader-package input layouts (plus elements the draw path must ignore),
@@ -187,7 +201,10 @@ def files_from_model_data(md: scene.ModelData, texture_paths: Optional[Sequence[
             layouts.append(key)
         prim_layout.append(layouts.index(key))
     objects = [dict(name="BSSolid", obj_type=4), dict(name="DSZTestWrite", obj_type=5), dict(name="RSMesh", obj_type=6),
-               dict(name="tAlbedoMap", obj_type=1), dict(name="SSLinear", obj_type=3), dict(name="CBMaterial", obj_type=0)]
+               dict(name="tAlbedoMap", obj_type=1), dict(name="SSLinear", obj_type=3), dict(name="CBMaterial", obj_type=0),
+               dict(name="BSBlendAlpha", obj_type=4), dict(name="BSAddAlpha", obj_type=4), dict(name="DSZTest", obj_type=5),
+               dict(name="DSZWrite", obj_type=5), dict(name="DSNone", obj_type=5), dict(name="RSMeshCN", obj_type=6),
+               dict(name="RSMeshCF", obj_type=6), dict(name="DSZTestWriteStencilWrite", obj_type=5)]
     for i, (els, stride) in enumerate(layouts):
         e = [("Normal", scene.IEF_S8N if hasattr(scene, "IEF_S8N") else 9, 3, 0, 0)]  # not bound by the draw path
         e += [(SEM_NAMES[sem], fmt, cnt, off, 0) for (sem, fmt, cnt, off) in els]
@@ -200,11 +217,15 @@ def files_from_model_data(md: scene.ModelData, texture_paths: Optional[Sequence[
     mats = []
     for p in range(md.nprims):
         t = int(md.prim_to_texture[p])
-        mats.append(dict(name=names[p], albedo=(t + 1) if t >= 0 else None, extra_states=[(2, "SSLinear", handle_of("SSLinear")),
-                                                                                            (1, "CBMaterial", 0)]))
+        mat = dict(name=names[p], albedo=(t + 1) if t >= 0 else None, extra_states=[(2, "SSLinear", handle_of("SSLinear")),
+                                                                                     (1, "CBMaterial", 0)])
+        if md.prim_states is not None:  # the material names the state objects that mean this primitive's state
+            b, dw, dt, cu = (int(x) for x in md.prim_states[p])
+            mat.update(bs=STATE_NAMES["bs"][b], ds=STATE_NAMES["ds"][(dw, dt)], rs=STATE_NAMES["rs"][cu])
+        mats.append(mat)
     rmaterial = write_rmaterial(paths, mats)
     rmodel = write_rmodel(md, [handle_of(f"IATest{i}", low=p) for p, i in enumerate(prim_layout)], names, list(range(md.nprims)))
-    rtextures = [write_rtexture(t.width, t.height, t.fmt, t.data) for t in md.textures]
+    rtextures = [write_rtexture(t.width, t.height, t.fmt, t.data, level_count=getattr(t, "levels", 1)) for t in md.textures]
     return rmodel, rshader2, rmaterial, rtextures
 
 

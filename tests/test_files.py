@@ -381,3 +381,31 @@ def test_parsers_under_address_sanitizer(tmp_path):
     assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
     ok, err = [int(t.split("=")[1]) for t in r.stdout.split()]
     assert ok > 1000 and err > 5000, r.stdout
+
+
+def test_state_object_names_map_to_material_states():
+    """row f-4: MT Framework state-object names -> (blend, depth write, depth test, cull); a convention of this build"""
+    A, OFF, ADD = 0, 1, 2
+    cases = {("BSSolid", "DSZTestWrite", "RSMesh"): ((OFF, 1, 1, 0), 3),
+             ("BSBlendAlpha", "DSZTest", "RSMeshCN"): ((A, 0, 1, 1), 3),
+             ("BSAddAlpha", "DSZWrite", "RSMeshCF"): ((ADD, 1, 0, 2), 3),
+             ("BSRevSubBlendAlpha", "DSZTestWriteStencilWrite", "RSMeshBias1"): ((A, 1, 1, 0), 3),
+             ("BSBlendBlendAlpha", "DSZTestStencilWrite", "RSTwoSide"): ((A, 0, 1, 1), 3),
+             (None, None, None): ((A, 1, 1, 0), 0),            # nothing named: the reference's pipeline state
+             ("", "Whatever", "xx"): ((A, 1, 1, 0), 0),        # unknown names fall back to it too
+             ("BSSolid", None, None): ((OFF, 1, 1, 0), 1)}
+    for names, want in cases.items():
+        assert files.state_from_names(*names) == want, names
+
+
+def test_states_from_files_follow_material_names():
+    from tests.pixel_scenes import pixel_model
+    prims = [dict(verts=[(1, 1, .5), (1, 9, .5), (9, 9, .5)], indices=[0, 1, 2]) for _ in range(4)]
+    md = pixel_model(prims)
+    md.prim_states = np.array([(0, 1, 1, 0), (1, 0, 1, 1), (2, 1, 0, 2), (1, 0, 0, 0)], dtype=np.uint8)
+    rmodel, rshader2, rmaterial, _ = mt_files.files_from_model_data(md)
+    sh = files.Shader2File(rshader2)
+    mat = files.MaterialFile(rmaterial, sh)
+    got = files.states_from_files(files.ModelFile(rmodel), sh, mat)
+    assert (got == md.prim_states).all(), got
+    mat.close(); sh.close()

@@ -72,3 +72,42 @@ def test_unknown_input_layout_handle_is_an_error(gpu_device):
     bad = mt_files.write_rmodel(md, [mt_files.handle_of("RSMesh")], ["mat_0"], [0])
     with pytest.raises(api.MtrError):
         files.model_from_files(gpu_device, files.ModelFile(bad), sh, None, [])
+
+
+def test_material_states_and_mip_chains_from_files(gpu_device):
+    """row f-4 end to end over files: the materials name state objects (BSAddAlpha, DSZTest, RSMeshCN ...), the textures carry
+    mip chains behind their offset tables; states applied by name and chains uploaded give the oracle's pixels"""
+    rng = np.random.default_rng(4)
+
+    def chain(w, h, levels, seed):
+        data, lw, lh = b"", w, h
+        for l in range(levels):
+            img = np.random.default_rng(seed + l).integers(0, 256, size=(lh, lw, 4), dtype=np.uint8)
+            img[..., 3] = np.where(img[..., 3] > 128, 255, 100)
+            data += img.tobytes()
+            lw, lh = max(1, lw >> 1), max(1, lh >> 1)
+        return scene.TextureData(w, h, scene.TEX_RGBA8, data, levels=levels)
+    tex = [chain(64, 64, 5, 1), chain(32, 16, 4, 9)]
+    prims = []
+    for i in range(10):
+        x0, y0 = rng.uniform(0, 30, size=2)
+        s = rng.uniform(4, 30)
+        z = float(rng.integers(1, 15)) / 16
+        v = [(x0, y0, z, 0, 0), (x0, y0 + s, z, 0, 1), (x0 + s, y0 + s, z, 1, 1), (x0 + s, y0, z, 1, 0)]
+        prims.append(dict(verts=v, indices=[0, 1, 2, 0, 2, 3] if i % 3 else [0, 2, 1, 0, 3, 2], texture=i % 2, debug_id=i))
+    md = pixel_model(prims, textures=tex)
+    md.prim_states = np.array([(rng.integers(0, 3), rng.integers(0, 2), rng.integers(0, 2), rng.integers(0, 3)) for _ in prims], dtype=np.uint8)
+    rmodel, rshader2, rmaterial, rtextures = mt_files.files_from_model_data(md)
+
+    def make(dev):
+        sh = files.Shader2File(rshader2)
+        mat = files.MaterialFile(rmaterial, sh)
+        mf = files.ModelFile(rmodel)
+        t = [files.TextureFile(b).upload(dev, max_levels=8) for b in rtextures]
+        m = files.model_from_files(dev, mf, sh, mat, t)
+        m.set_prim_states(files.states_from_files(mf, sh, mat))
+        return m
+    M = pixel_to_ndc_matrix(64, 64)
+    ref = render_oracle(64, 64, [dict(md=md, M=M)])
+    got = render_gpu(gpu_device, 64, 64, [dict(md=md, M=M, make_model=make)])
+    assert_same(got, ref, "states + mips from files")
