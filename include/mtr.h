@@ -204,6 +204,12 @@ int32_t mtr_frame_draw_batch(mtr_frame *frame, mtr_batch *batch, const float vie
 int32_t mtr_frame_draw_instances(mtr_frame *frame, mtr_model *model, const float *model_mats,
                                  const float *palettes, size_t npal, size_t n,
                                  const float view_proj[16]);
+/* The per-joint cubes Model::render adds to the debug overlay every frame (src/model.rs:309-315): one cube per joint at
+ * joint_position * 0.01 with scale 0.005 (from_scale_rotation_translation, src/debug_overlay.rs:227-231), drawn like
+ * mtr_frame_draw_overlay_cubes.  The positions are JointInfo::offset of every joint (src/model.rs:283-291), given with
+ * mtr_model_set_joint_positions (mtr_model_create_from_files sets them).  A model without joints draws nothing. */
+int32_t mtr_model_set_joint_positions(mtr_model *model, const float *xyz, size_t njoints);
+int32_t mtr_frame_draw_model_joints(mtr_frame *frame, mtr_model *model, const float camera[16]);
 /* DebugOverlay::render (src/debug_overlay.rs:202-221): n instanced cubes, no blend, constant colour */
 int32_t mtr_frame_draw_overlay_cubes(mtr_frame *frame, const float camera[16], const float *inst_mats,
                                      size_t n);

@@ -71,6 +71,19 @@ int32_t mtr_rmodel_boundary_joint(const mtr_rmodel_view *m, uint32_t i, uint32_t
 int32_t mtr_rmodel_joint(const mtr_rmodel_view *m, uint32_t i, uint32_t *no, uint32_t *parent, uint32_t *symmetry,
                          float offset[3]);
 
+/* Skin palette of a model's skeleton (row f-3; the reference parses lmats / imats / joint_table and never combines them,
+ * src/rmodel.rs:392-413, so this formation rule is the build's -- the usual one for MT Framework data):
+ *     world_j = world_parent(j) * local_j      (parent 255, or a joint that is its own parent: world_j = local_j)
+ *     palette[j] = world_j * imat_j            (imat_j = inverse of the bind-pose world matrix)
+ * j is the joint's INDEX in the file's joint array, which is what the vertex `Joint` bytes hold; joint_table maps a joint
+ * NUMBER (JointInfo::no) to that index (mtr_rmodel_joint_index).  local_mats: jnt_num matrices, or NULL for the file's
+ * lmats (the bind pose, which must give the identity wherever the file is consistent).  Matrices are the file's 16 floats
+ * read as column-major M * v (MtMatrix rows = glam columns); every product is the fma chain of SPEC.md section 4.
+ * out_palette: jnt_num * 16 floats for mtr_model_set_palette.  MTR_E_INVALID: no joints, a parent outside the array, a cycle. */
+int32_t mtr_rmodel_palette(const mtr_rmodel_view *m, const float *local_mats, float *out_palette, size_t cap_mats);
+/* index of the joint numbered `no` (joint_table[no]), or -1 */
+int32_t mtr_rmodel_joint_index(const mtr_rmodel_view *m, uint32_t no);
+
 /* -------------------------------------------------------------- rTexture ---- */
 typedef struct mtr_rtexture_view {
     uint32_t version, prebias, type, level_count, array_count, format; /* format: MTR_TEX_* when supported */
@@ -168,13 +181,37 @@ int32_t mtr_rscheduler_track(const mtr_rscheduler *s, uint32_t i, mtr_track_info
 /* key k of track i: frame number (24 bits), mode (8 bits), and the value as the reference decodes it
  * (src/rscheduler.rs:146-205): BOOL -> u8, INT -> u32, FLOAT -> f32 (bit pattern in value_bits),
  * RESOURCE -> class hash in value_bits and the path in *resource (NULL for a null reference).
- * Other key types (VECTOR / MATRIX / ...: todo!() in the reference) return MTR_E_UNSUPPORTED. */
+ * VECTOR / MATRIX keys: mtr_rscheduler_key_floats.  Other key types (INT64, STRING, ...: todo!() in the reference) return
+ * MTR_E_UNSUPPORTED. */
 int32_t mtr_rscheduler_key(const mtr_rscheduler *s, uint32_t track, uint32_t k, uint32_t *frame, uint32_t *mode,
                            uint64_t *value_bits, const char **resource);
 /* value of a BOOL / INT / FLOAT track at `frame`: the key with the greatest frame number <= frame (step hold; the
  * reference never evaluates tracks, so this rule is this build's and is documented as such).  MTR_E_INVALID if the
  * track has no key at or before `frame`. */
 int32_t mtr_rscheduler_eval(const mtr_rscheduler *s, uint32_t track, uint32_t frame, uint64_t *value_bits);
+/* VECTOR (4 f32 per key) and MATRIX (16 f32 per key) tracks -- `todo!()` in the reference (src/rscheduler.rs:207), decoded
+ * here as MtVector4 / MtMatrix arrays.  key_floats: the floats of key k (out: 4 or 16, *n says which); eval_floats: the
+ * key with the greatest frame number <= frame (step hold), as mtr_rscheduler_eval.  FLOAT tracks answer with n = 1. */
+int32_t mtr_rscheduler_key_floats(const mtr_rscheduler *s, uint32_t track, uint32_t k, float out[16], uint32_t *n);
+int32_t mtr_rscheduler_eval_floats(const mtr_rscheduler *s, uint32_t track, uint32_t frame, float out[16], uint32_t *n);
+/* first track with this name, or -1 */
+int32_t mtr_rscheduler_find_track(const mtr_rscheduler *s, const char *name);
+/* Binding tracks to what the draw path animates (row f-2).  The reference never evaluates a track, so WHICH track drives
+ * WHAT is the host's statement: one binding = (track, target, index).  mtr_rscheduler_apply evaluates every binding at
+ * `frame` (step hold) into the caller's arrays, ready for mtr_model_set_parts_disp and mtr_batch_create / _update:
+ *   MTR_SDL_PARTS_DISP          BOOL / INT track   -> parts_disp[index] = value != 0
+ *   MTR_SDL_INSTANCE_MATRIX     MATRIX track       -> model_mats[index] = the 16 floats
+ *   MTR_SDL_INSTANCE_TRANSLATION VECTOR track      -> floats 12..14 of model_mats[index] = x, y, z
+ *   MTR_SDL_INSTANCE_TRANSLATE_X / _Y / _Z  FLOAT track -> float 12 / 13 / 14 of model_mats[index]
+ * A binding whose track has no key at or before `frame` leaves its target untouched.  MTR_E_INVALID: track / index out of
+ * range, or a track of the wrong type for its target. */
+enum { MTR_SDL_PARTS_DISP = 0, MTR_SDL_INSTANCE_MATRIX = 1, MTR_SDL_INSTANCE_TRANSLATION = 2, MTR_SDL_INSTANCE_TRANSLATE_X = 3,
+       MTR_SDL_INSTANCE_TRANSLATE_Y = 4, MTR_SDL_INSTANCE_TRANSLATE_Z = 5 };
+typedef struct mtr_sdl_binding {
+    uint32_t track, target, index;
+} mtr_sdl_binding;
+int32_t mtr_rscheduler_apply(const mtr_rscheduler *s, uint32_t frame, const mtr_sdl_binding *bindings, size_t nbindings,
+                             uint8_t *parts_disp, size_t nparts, float *model_mats, size_t ninstances);
 
 /* -------------------------------------------------------------- rArchive ---- */
 /* ArchiveFile over a caller-owned file image (zlib-compressed resources behind a table of 0x90-byte entries).
@@ -205,7 +242,8 @@ int32_t mtr_rarchive_extract(const mtr_rarchive_view *a, uint32_t i, void *out, 
  * handle (missing -> MTR_E_INVALID, the reference panics), the texture through material name -> rMaterial ->
  * albedo texture index -> textures[] (the caller loads rmaterial texture i into textures[i]; NULL = could not be
  * loaded, an error only if a primitive needs it: "no texture found!", src/model.rs:167), the debug id from the
- * primitive's boundary joint.  `mat` may be NULL (every primitive untextured). */
+ * primitive's boundary joint.  `mat` may be NULL (every primitive untextured).  The joints' offsets become the model's
+ * joint positions (src/model.rs:283-291) for mtr_frame_draw_model_joints. */
 int32_t mtr_model_create_from_files(mtr_device *dev, const mtr_rmodel_view *model, const mtr_rshader2 *sh,
                                     const mtr_rmaterial *mat, mtr_texture *const *textures, size_t ntextures,
                                     mtr_model **out);

@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_synchronize", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
+    "mtr_device_synchronize", "mtr_model_set_joint_positions", "mtr_frame_draw_model_joints", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
     "mtr_frame_unpack_color_shards_on_stream", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
@@ -96,6 +96,8 @@ def _load() -> C.CDLL:
         "mtr_texture_create": (i32, [vp, u32, u32, u32, vp, sz, C.POINTER(vp)]),
         "mtr_texture_create_mips": (i32, [vp, u32, u32, u32, u32, vp, sz, C.POINTER(vp)]),
         "mtr_model_set_prim_states": (i32, [vp, vp, sz]),
+        "mtr_model_set_joint_positions": (i32, [vp, vp, sz]),
+        "mtr_frame_draw_model_joints": (i32, [vp, vp, vp]),
         "mtr_texture_destroy": (None, [vp]),
         "mtr_texture_read_rgba8": (i32, [vp, vp, sz]),
         "mtr_model_create": (i32, [vp, vp, sz, vp, sz, vp, sz, vp, vp, vp, sz, vp, C.POINTER(vp)]),
@@ -327,10 +329,19 @@ class Model:
             m = _f32(mats, (-1, 16))
             self.dev.check(lib.mtr_model_set_palette(self._h, _p(m), m.shape[0]))
 
-    def render(self, frame: "Frame", view_proj: np.ndarray):
+    def render(self, frame: "Frame", view_proj: np.ndarray, joints: bool = False):
         """Model::render(rpass, queue, transform_bind_group, debug_overlay) -- src/model.rs:299-305; the
-        transform uniform (src/bin/modelviewer.rs:217-221) is passed directly."""
+        transform uniform (src/bin/modelviewer.rs:217-221) is passed directly.  joints: also the per-joint debug cubes the
+        reference adds to its overlay every frame (src/model.rs:309-315)."""
         frame.draw_model(self, view_proj)
+        if joints:
+            vp = _f32(view_proj, 16)
+            self.dev.check(lib.mtr_frame_draw_model_joints(frame._h, self._h, _p(vp)))
+
+    def set_joint_positions(self, xyz: np.ndarray):
+        """JointInfo::offset of every joint (src/model.rs:283-291)"""
+        a = _f32(xyz).reshape(-1, 3)
+        self.dev.check(lib.mtr_model_set_joint_positions(self._h, _p(a), a.shape[0]))
 
     def vertex_stage(self, prim: int, M: np.ndarray):
         from .scene import unpack_primitive

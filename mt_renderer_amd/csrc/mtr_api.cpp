@@ -208,6 +208,7 @@ struct mtr_model {
     std::vector<mtr_texture*> textures;
     std::vector<uint32_t> debug_rgba8;
     std::vector<mtr_prim_state> states;  // material state per primitive, empty: the reference's pipeline state
+    std::vector<float> joint_cubes;      // one instance matrix per joint: scale 0.005, translation = offset * 0.01 (src/model.rs:309-315)
     std::vector<DChunk> chunks;
     uint64_t ntris_visible = 0;
     bool chunks_dirty = true;
@@ -1320,6 +1321,25 @@ int32_t mtr_frame_draw_instances(mtr_frame* f, mtr_model* m, const float* model_
     if (rc) { mtr_batch_destroy(b); return rc; }
     f->draws.back().owned_batch.reset(b);
     return MTR_OK;
+}
+
+int32_t mtr_model_set_joint_positions(mtr_model* m, const float* xyz, size_t n) {
+    if (!m || (!xyz && n)) return MTR_E_INVALID;
+    if (n > 0xFFFF) return fail(m->dev, MTR_E_INVALID, "too many joints");
+    m->joint_cubes.assign(n * 16, 0.0f);
+    for (size_t j = 0; j < n; j++) {
+        float* M = &m->joint_cubes[j * 16];  // glam::Mat4::from_scale_rotation_translation(splat(0.005), IDENTITY, pos * 0.01)
+        M[0] = M[5] = M[10] = 0.005f;
+        M[12] = xyz[3 * j + 0] * 0.01f; M[13] = xyz[3 * j + 1] * 0.01f; M[14] = xyz[3 * j + 2] * 0.01f;
+        M[15] = 1.0f;
+    }
+    return MTR_OK;
+}
+
+int32_t mtr_frame_draw_model_joints(mtr_frame* f, mtr_model* m, const float camera[16]) {
+    if (!f || !m || !camera) return MTR_E_INVALID;
+    if (m->dev != f->dev) return fail(f->dev, MTR_E_INVALID, "model belongs to another device");
+    return mtr_frame_draw_overlay_cubes(f, camera, m->joint_cubes.data(), m->joint_cubes.size() / 16);
 }
 
 int32_t mtr_frame_draw_overlay_cubes(mtr_frame* f, const float camera[16], const float* inst_mats, size_t n) {

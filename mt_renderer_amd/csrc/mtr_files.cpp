@@ -4,6 +4,8 @@
 // (src/rmodel.rs:487-494, src/rtexture.rs:168-172, src/rshader2.rs:573-582, src/rmaterial.rs:317-322,
 // src/rscheduler.rs:221-223).  Nothing here trusts an offset or a count read from the file: every access
 // goes through Span::at(), which fails the parse instead of reading out of bounds (the reference panics).
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -203,6 +205,8 @@ struct mtr_rscheduler {
         std::vector<uint64_t> values;     // decoded values (see mtr_rscheduler_key)
         std::vector<std::string> res;     // RESOURCE paths ("" + has_res false for null)
         std::vector<uint8_t> has_res;
+        std::vector<float> fvalues;       // VECTOR (4 per key) / MATRIX (16 per key) tracks
+        uint32_t fwidth = 0;
         bool decodable = false;
     };
     std::vector<Track> tracks;
@@ -647,6 +651,12 @@ int32_t mtr_rscheduler_parse(const void* data, size_t len, mtr_rscheduler** out)
                 case 13: vsz = 8; break;  // RESOURCE
                 default: vsz = 0;         // todo!() in the reference once a key exists
             }
+            if (tr.track_type == 8 || tr.track_type == 16) {  // VECTOR = MtVector4, MATRIX = MtMatrix (todo!() in the reference)
+                tr.fwidth = tr.track_type == 8 ? 4 : 16;
+                if (!s.at(t.key_value, tr.key_num, (uint64_t)tr.fwidth * 4)) return fail("key values out of range", i);
+                tr.fvalues.resize((size_t)tr.key_num * tr.fwidth);
+                if (tr.key_num) memcpy(tr.fvalues.data(), s.p + t.key_value, tr.fvalues.size() * 4);
+            }
             if (vsz) {
                 if (tr.track_type == 11 && tr.prop_type != 3) return fail("BOOL track whose property is not bool", i);   // asserts,
                 if (tr.track_type == 9 && tr.prop_type != 12) return fail("FLOAT track whose property is not f32", i);   // :147,:165
@@ -712,6 +722,133 @@ int32_t mtr_rscheduler_eval(const mtr_rscheduler* s, uint32_t track, uint32_t fr
     }
     if (best < 0) return ferr(MTR_E_INVALID, "rScheduler: track %u has no key at or before frame %u", track, frame);
     *value_bits = t.values[(size_t)best];
+    return MTR_OK;
+}
+
+static int64_t held_key(const mtr_rscheduler::Track& t, uint32_t frame) {
+    int64_t best = -1;
+    uint32_t best_frame = 0;
+    for (size_t k = 0; k < t.frames.size(); k++) {
+        const uint32_t f = t.frames[k] & 0xffffff;
+        if (f <= frame && (best < 0 || f >= best_frame)) { best = (int64_t)k; best_frame = f; }
+    }
+    return best;
+}
+
+int32_t mtr_rscheduler_key_floats(const mtr_rscheduler* s, uint32_t track, uint32_t k, float out[16], uint32_t* n) {
+    if (!s || !out || !n || track >= s->tracks.size()) return ferr(MTR_E_INVALID, "rScheduler: track %u out of range", track);
+    const auto& t = s->tracks[track];
+    if (k >= t.frames.size()) return ferr(MTR_E_INVALID, "rScheduler: key %u of track %u out of range", k, track);
+    if (t.track_type == 9 && t.decodable) {
+        const uint32_t bits = (uint32_t)t.values[k];
+        memcpy(out, &bits, 4);
+        *n = 1;
+        return MTR_OK;
+    }
+    if (!t.fwidth) return ferr(MTR_E_UNSUPPORTED, "rScheduler: track type %u has no float keys", t.track_type);
+    memcpy(out, &t.fvalues[(size_t)k * t.fwidth], (size_t)t.fwidth * 4);
+    *n = t.fwidth;
+    return MTR_OK;
+}
+
+int32_t mtr_rscheduler_eval_floats(const mtr_rscheduler* s, uint32_t track, uint32_t frame, float out[16], uint32_t* n) {
+    if (!s || !out || !n || track >= s->tracks.size()) return ferr(MTR_E_INVALID, "rScheduler: track %u out of range", track);
+    const int64_t k = held_key(s->tracks[track], frame);
+    if (k < 0) return ferr(MTR_E_INVALID, "rScheduler: track %u has no key at or before frame %u", track, frame);
+    return mtr_rscheduler_key_floats(s, track, (uint32_t)k, out, n);
+}
+
+int32_t mtr_rscheduler_find_track(const mtr_rscheduler* s, const char* name) {
+    if (!s || !name) return -1;
+    for (size_t i = 0; i < s->tracks.size(); i++)
+        if (s->tracks[i].name == name) return (int32_t)i;
+    return -1;
+}
+
+int32_t mtr_rscheduler_apply(const mtr_rscheduler* s, uint32_t frame, const mtr_sdl_binding* b, size_t nb, uint8_t* parts_disp, size_t nparts,
+                             float* model_mats, size_t ninst) {
+    if (!s || (!b && nb)) return ferr(MTR_E_INVALID, "rScheduler: null argument");
+    for (size_t i = 0; i < nb; i++) {
+        if (b[i].track >= s->tracks.size()) return ferr(MTR_E_INVALID, "binding %zu: track %u out of range", i, b[i].track);
+        const auto& t = s->tracks[b[i].track];
+        const int64_t k = held_key(t, frame);
+        if (b[i].target == MTR_SDL_PARTS_DISP) {
+            if ((t.track_type != 11 && t.track_type != 6) || !t.decodable) return ferr(MTR_E_INVALID, "binding %zu: parts_disp needs a BOOL / INT track", i);
+            if (!parts_disp || b[i].index >= nparts) return ferr(MTR_E_INVALID, "binding %zu: parts_disp index %u out of range", i, b[i].index);
+            if (k >= 0) parts_disp[b[i].index] = t.values[(size_t)k] != 0;
+            continue;
+        }
+        if (!model_mats || b[i].index >= ninst) return ferr(MTR_E_INVALID, "binding %zu: instance %u out of range", i, b[i].index);
+        float* M = model_mats + (size_t)b[i].index * 16;
+        const uint32_t need = b[i].target == MTR_SDL_INSTANCE_MATRIX ? 16u : (b[i].target == MTR_SDL_INSTANCE_TRANSLATION ? 4u : 1u);
+        if (b[i].target > MTR_SDL_INSTANCE_TRANSLATE_Z) return ferr(MTR_E_INVALID, "binding %zu: unknown target %u", i, b[i].target);
+        const uint32_t have = t.track_type == 9 && t.decodable ? 1u : t.fwidth;
+        if (have != need) return ferr(MTR_E_INVALID, "binding %zu: track type %u does not fit target %u", i, t.track_type, b[i].target);
+        if (k < 0) continue;
+        float v[16];
+        uint32_t n = 0;
+        const int32_t rc = mtr_rscheduler_key_floats(s, b[i].track, (uint32_t)k, v, &n);
+        if (rc) return rc;
+        if (need == 16) memcpy(M, v, 64);
+        else if (need == 4) memcpy(M + 12, v, 12);
+        else M[12 + (b[i].target - MTR_SDL_INSTANCE_TRANSLATE_X)] = v[0];
+    }
+    return MTR_OK;
+}
+
+// -------------------------------------------------------------------------------------------- skin palette
+int32_t mtr_rmodel_joint_index(const mtr_rmodel_view* m, uint32_t no) {
+    if (!m || !m->joint_table || no > 255) return -1;
+    const uint8_t idx = m->joint_table[no];
+    return (idx == 255 || idx >= m->jnt_num) ? -1 : (int32_t)idx;
+}
+
+static void mat4_mul_fma(const float* A, const float* B, float* out) {  // SPEC.md section 4: k-ordered fma chain from 0
+    float r[16];
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++) {
+            float a = 0.0f;
+            for (int k = 0; k < 4; k++) a = std::fmaf(A[k * 4 + i], B[c * 4 + k], a);
+            r[c * 4 + i] = a;
+        }
+    memcpy(out, r, sizeof r);
+}
+
+int32_t mtr_rmodel_palette(const mtr_rmodel_view* m, const float* local_mats, float* out, size_t cap) {
+    if (!m || !out) return ferr(MTR_E_INVALID, "palette: null argument");
+    const uint32_t n = m->jnt_num;
+    if (n == 0 || !m->joint_infos || !m->lmats || !m->imats) return ferr(MTR_E_INVALID, "palette: the model has no joints");
+    if (cap < n) return ferr(MTR_E_INVALID, "palette: room for %zu matrices, the model has %u joints", cap, n);
+    std::vector<float> locals((size_t)n * 16), imats((size_t)n * 16), world((size_t)n * 16);
+    memcpy(locals.data(), local_mats ? local_mats : m->lmats, locals.size() * 4);  // the file's arrays may be unaligned
+    memcpy(imats.data(), m->imats, imats.size() * 4);
+    std::vector<uint8_t> state(n, 0);  // 0 new, 1 on the stack, 2 done
+    for (uint32_t j0 = 0; j0 < n; j0++) {
+        // walk up to the first finished ancestor, then come back down
+        std::vector<uint32_t> chain;
+        uint32_t j = j0;
+        while (state[j] != 2) {
+            if (state[j] == 1) return ferr(MTR_E_INVALID, "palette: joint %u is its own ancestor", j);
+            state[j] = 1;
+            chain.push_back(j);
+            uint32_t no, parent, sym;
+            float off[3];
+            mtr_rmodel_joint(m, j, &no, &parent, &sym, off);
+            if (parent == 255 || parent == j) break;
+            if (parent >= n) return ferr(MTR_E_INVALID, "palette: joint %u has parent %u of %u joints", j, parent, n);
+            j = parent;
+        }
+        for (size_t k = chain.size(); k-- > 0;) {
+            const uint32_t c = chain[k];
+            uint32_t no, parent, sym;
+            float off[3];
+            mtr_rmodel_joint(m, c, &no, &parent, &sym, off);
+            if (parent == 255 || parent == c) memcpy(&world[(size_t)c * 16], &locals[(size_t)c * 16], 64);
+            else mat4_mul_fma(&world[(size_t)parent * 16], &locals[(size_t)c * 16], &world[(size_t)c * 16]);
+            state[c] = 2;
+        }
+    }
+    for (uint32_t j = 0; j < n; j++) mat4_mul_fma(&world[(size_t)j * 16], &imats[(size_t)j * 16], out + (size_t)j * 16);
     return MTR_OK;
 }
 
@@ -812,7 +949,15 @@ int32_t mtr_model_create_from_files(mtr_device* dev, const mtr_rmodel_view* mode
     }
     const int32_t rc = mtr_model_create(dev, model->vertex_buf, model->vertexbuf_size, model->index_buf, model->index_num, prims.data(), np,
                                         layouts.data(), p2t.data(), loaded.data(), loaded.size(), dids.data(), out);
-    if (rc) ferr(rc, "Model::new: %s", mtr_last_error(dev));
+    if (rc) return ferr(rc, "Model::new: %s", mtr_last_error(dev));
+    if (model->jnt_num && model->joint_infos) {  // joint_positions, src/model.rs:283-291
+        std::vector<float> pos((size_t)model->jnt_num * 3);
+        for (uint32_t j = 0; j < model->jnt_num; j++) {
+            uint32_t no, parent, sym;
+            mtr_rmodel_joint(model, j, &no, &parent, &sym, &pos[(size_t)j * 3]);
+        }
+        mtr_model_set_joint_positions(*out, pos.data(), model->jnt_num);
+    }
     return rc;
 }
 

@@ -19,7 +19,8 @@ from .api import MtrError, lib
 EXPORTED_SYMBOLS = [
     "mtr_files_last_error", "mtr_file_struct_size", "mtr_rmodel_parse", "mtr_primitive_field", "mtr_rmodel_boundary_joint",
     "mtr_rmodel_joint", "mtr_rtexture_parse", "mtr_texture_create_from_file", "mtr_texture_create_from_file_mips",
-    "mtr_state_from_names", "mtr_model_states_from_files", "mtr_rshader2_parse", "mtr_rshader2_destroy",
+    "mtr_state_from_names", "mtr_model_states_from_files", "mtr_rmodel_palette", "mtr_rmodel_joint_index", "mtr_rscheduler_key_floats",
+    "mtr_rscheduler_eval_floats", "mtr_rscheduler_find_track", "mtr_rscheduler_apply", "mtr_rshader2_parse", "mtr_rshader2_destroy",
     "mtr_rshader2_num_objects", "mtr_rshader2_object", "mtr_rshader2_find", "mtr_rshader2_input_layout",
     "mtr_rmaterial_parse", "mtr_rmaterial_destroy", "mtr_rmaterial_num_textures", "mtr_rmaterial_texture_path",
     "mtr_rmaterial_num_materials", "mtr_rmaterial_info", "mtr_rmaterial_find", "mtr_rscheduler_parse",
@@ -99,6 +100,12 @@ lib.mtr_rmodel_joint.argtypes = [C.POINTER(_RModelView), C.c_uint32, C.POINTER(C
 lib.mtr_rtexture_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_RTextureView)]
 lib.mtr_texture_create_from_file.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
 lib.mtr_texture_create_from_file_mips.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p)]
+lib.mtr_rmodel_palette.argtypes = [C.POINTER(_RModelView), C.c_void_p, C.c_void_p, C.c_size_t]
+lib.mtr_rmodel_joint_index.argtypes = [C.POINTER(_RModelView), C.c_uint32]
+lib.mtr_rscheduler_key_floats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+lib.mtr_rscheduler_eval_floats.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+lib.mtr_rscheduler_find_track.argtypes = [C.c_void_p, C.c_char_p]
+lib.mtr_rscheduler_apply.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
 lib.mtr_state_from_names.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p]
 lib.mtr_model_states_from_files.argtypes = [C.POINTER(_RModelView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
 lib.mtr_rshader2_parse.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -132,6 +139,9 @@ lib.mtr_rscheduler_key.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER
 lib.mtr_rscheduler_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
 lib.mtr_model_create_from_files.argtypes = [C.c_void_p, C.POINTER(_RModelView), C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p)]
+
+
+SDL_PARTS_DISP, SDL_INSTANCE_MATRIX, SDL_INSTANCE_TRANSLATION, SDL_INSTANCE_TRANSLATE_X, SDL_INSTANCE_TRANSLATE_Y, SDL_INSTANCE_TRANSLATE_Z = range(6)
 
 
 def _check(rc: int):
@@ -195,6 +205,20 @@ class ModelFile:
 
     def imats(self) -> np.ndarray:
         return self._arr(self.v.imats, self.v.jnt_num * 64, np.float32).reshape(-1, 16)
+
+    def palette(self, local_mats: Optional[np.ndarray] = None) -> np.ndarray:
+        """skin palette of the skeleton (include/mtr_files.h: mtr_rmodel_palette): [jnt_num, 16] f32 for Model.set_palette;
+        local_mats None = the file's bind pose"""
+        n = self.v.jnt_num
+        out = np.zeros((max(1, n), 16), dtype=np.float32)
+        lm = None if local_mats is None else np.ascontiguousarray(local_mats, dtype=np.float32).reshape(n, 16)
+        _check(lib.mtr_rmodel_palette(C.byref(self.v), None if lm is None else lm.ctypes.data_as(C.c_void_p),
+                                      out.ctypes.data_as(C.c_void_p), n))
+        return out[:n]
+
+    def joint_index(self, no: int) -> Optional[int]:
+        i = lib.mtr_rmodel_joint_index(C.byref(self.v), no)
+        return None if i < 0 else i
 
     def joint_table(self) -> np.ndarray:
         return self._arr(self.v.joint_table, 256) if self.v.joint_table else np.full(256, 255, dtype=np.uint8)
@@ -333,6 +357,34 @@ class SchedulerFile:
         val = C.c_uint64()
         _check(lib.mtr_rscheduler_eval(self.h, track, frame, C.byref(val)))
         return val.value
+
+    def key_floats(self, track: int, k: int) -> np.ndarray:
+        """FLOAT (1) / VECTOR (4) / MATRIX (16) key as f32"""
+        out = np.zeros(16, dtype=np.float32)
+        n = C.c_uint32()
+        _check(lib.mtr_rscheduler_key_floats(self.h, track, k, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out[:n.value].copy()
+
+    def eval_floats(self, track: int, frame: int) -> np.ndarray:
+        out = np.zeros(16, dtype=np.float32)
+        n = C.c_uint32()
+        _check(lib.mtr_rscheduler_eval_floats(self.h, track, frame, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out[:n.value].copy()
+
+    def find_track(self, name: str) -> Optional[int]:
+        i = lib.mtr_rscheduler_find_track(self.h, name.encode())
+        return None if i < 0 else i
+
+    def apply(self, frame: int, bindings, parts_disp: Optional[np.ndarray] = None, model_mats: Optional[np.ndarray] = None):
+        """bindings: (track, target, index) triples (include/mtr_files.h: MTR_SDL_*); the arrays are updated in place"""
+        b = np.ascontiguousarray(bindings, dtype=np.uint32).reshape(-1, 3)
+        pd = None if parts_disp is None else parts_disp
+        mm = None if model_mats is None else model_mats
+        assert pd is None or (pd.dtype == np.uint8 and pd.flags.c_contiguous)
+        assert mm is None or (mm.dtype == np.float32 and mm.flags.c_contiguous)
+        _check(lib.mtr_rscheduler_apply(self.h, frame, b.ctypes.data_as(C.c_void_p), b.shape[0],
+                                        None if pd is None else pd.ctypes.data_as(C.c_void_p), 0 if pd is None else pd.size,
+                                        None if mm is None else mm.ctypes.data_as(C.c_void_p), 0 if mm is None else mm.size // 16))
 
     def eval_float(self, track: int, frame: int) -> float:
         return float(np.array([self.eval(track, frame) & 0xFFFFFFFF], dtype=np.uint32).view(np.float32)[0])

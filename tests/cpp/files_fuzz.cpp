@@ -18,6 +18,7 @@ uint32_t mtr_crc32(const uint8_t* bytes, size_t len, uint32_t init) {  // src/ut
     return v;
 }
 const char* mtr_last_error(const mtr_device*) { return "stub"; }
+int32_t mtr_model_set_joint_positions(mtr_model*, const float*, size_t) { return MTR_OK; }
 int32_t mtr_texture_create(mtr_device*, uint32_t, uint32_t, uint32_t, const void*, size_t, mtr_texture**) { return MTR_E_HIP; }
 // reads every byte it is handed, so a mip chain gathered from offsets outside the file would trip ASan
 int32_t mtr_texture_create_mips(mtr_device*, uint32_t, uint32_t, uint32_t, uint32_t, const void* data, size_t len, mtr_texture**) {

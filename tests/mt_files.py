@@ -168,7 +168,8 @@ def write_rmodel(md: scene.ModelData, prim_layout_handle: Sequence[int], materia
         ji = b"".join(struct.pack("<Iff3f", (no & 0xFF) | ((parent & 0xFF) << 8) | (0xFF << 16), 1.0, 2.0, *off) for (no, parent, off) in joints)
         lm = np.ascontiguousarray(lmats, dtype="<f4").reshape(jn, 16).tobytes()
         im = np.ascontiguousarray(imats, dtype="<f4").reshape(jn, 16).tobytes()
-        table = bytes([i if i < jn else 255 for i in range(256)])
+        by_no = {no & 0xFF: i for i, (no, _p, _o) in enumerate(joints)}  # joint number -> index in the joint array
+        table = bytes([by_no.get(i, 255) for i in range(256)])
         joint_info = put(ji + lm + im + table, 8)
     parts_n = int(max(scene.unpack_primitive(md.prims[p])["parts_no"] for p in range(np_))) + 1 if np_ else 0
     parts = b"".join(struct.pack("<I3I4f", i, 0, 0, 0, 0.0, 0.0, 0.0, 1.0) for i in range(parts_n))
@@ -281,8 +282,10 @@ def write_rscheduler(tracks: Sequence[dict], version: int = 0x16, magic: bytes =
                         _pad(meta, 4)
                         data += struct.pack("<Q", len(meta))
                         meta += struct.pack("<I", v[0]) + v[1].encode() + b"\0"
+                elif tt == 16:
+                    data += struct.pack("<16f", *v)  # MATRIX: MtMatrix
                 else:
-                    data += struct.pack("<4f", *v)
+                    data += struct.pack("<4f", *v)   # VECTOR: MtVector4
         recs.append((t, name_off, kf, kv, len(keys)))
     _pad(data, 8)
     metadata = base + len(data)

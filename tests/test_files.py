@@ -409,3 +409,89 @@ def test_states_from_files_follow_material_names():
     got = files.states_from_files(files.ModelFile(rmodel), sh, mat)
     assert (got == md.prim_states).all(), got
     mat.close(); sh.close()
+
+
+def _translate(x, y, z):
+    m = np.eye(4, dtype=np.float64)
+    m[:3, 3] = (x, y, z)
+    return m
+
+
+def _chain_skeleton(jn=6):
+    """joint j hangs off joint j - 1 at an exactly representable offset; imat = inverse bind world matrix"""
+    offs = [(0.5 * j, 0.25, -0.125 * j) for j in range(jn)]
+    lm = np.stack([scene.to_f32_colmajor(_translate(*o)) for o in offs])
+    world, acc = [], np.zeros(3)
+    for o in offs:
+        acc = acc + np.array(o)
+        world.append(acc.copy())
+    im = np.stack([scene.to_f32_colmajor(_translate(*(-w))) for w in world])
+    joints = [(j + 10, (j - 1) if j else 255, offs[j]) for j in range(jn)]  # joint numbers differ from indices
+    return joints, lm, im, world
+
+
+def test_skeleton_palette_bind_pose_is_identity_and_animates():
+    """row f-3: palette[j] = world_j * imat_j, world_j = world_parent * local_j (this build's rule; the reference parses the
+    matrices and never combines them, src/rmodel.rs:392-413)"""
+    md = _model()
+    joints, lm, im, world = _chain_skeleton()
+    mf = files.ModelFile(mt_files.write_rmodel(md, [0, 0, 0], ["a", "b", "c"], [0, 1, 2], joints=joints, lmats=lm, imats=im))
+    pal = mf.palette()
+    assert pal.shape == (6, 16) and (pal == np.eye(4, dtype=np.float32).reshape(16)).all(), "bind pose must skin with the identity, exactly"
+    assert mf.joint_index(12) == 2 and mf.joint_index(10) == 0 and mf.joint_index(3) is None
+    # rotate joint 2 about z by 90 degrees: joints 0, 1 stay put, joints 2.. swing around joint 2's position
+    local = lm.copy().reshape(6, 4, 4)
+    R = np.array([[0, -1, 0, 0], [1, 0, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
+    local[2] = (_translate(*joints[2][2]) @ R).T.astype(np.float32)  # column-major storage = transpose of the row-major array
+    pal = mf.palette(local.reshape(6, 16)).reshape(6, 4, 4).transpose(0, 2, 1).astype(np.float64)
+    assert np.allclose(pal[0], np.eye(4)) and np.allclose(pal[1], np.eye(4))
+    for j in (2, 3, 5):
+        # a point at joint j's bind position: stays for j = 2 (the pivot), moves on a quarter circle around it otherwise
+        p = np.append(world[j], 1.0)
+        rel = world[j] - world[2]
+        want = world[2] + np.array([-rel[1], rel[0], rel[2]])
+        assert np.allclose((pal[j] @ p)[:3], want, atol=1e-6), j
+    # malformed skeletons
+    bad = list(joints); bad[1] = (11, 4, joints[1][2]); bad[4] = (14, 1, joints[4][2])  # 1 -> 4 -> 1
+    with pytest.raises(api.MtrError, match="ancestor"):
+        files.ModelFile(mt_files.write_rmodel(md, [0, 0, 0], ["a", "b", "c"], [0, 1, 2], joints=bad, lmats=lm, imats=im)).palette()
+    bad = list(joints); bad[3] = (13, 77, joints[3][2])
+    with pytest.raises(api.MtrError, match="parent"):
+        files.ModelFile(mt_files.write_rmodel(md, [0, 0, 0], ["a", "b", "c"], [0, 1, 2], joints=bad, lmats=lm, imats=im)).palette()
+    with pytest.raises(api.MtrError, match="no joints"):
+        files.ModelFile(mt_files.write_rmodel(md, [0, 0, 0], ["a", "b", "c"], [0, 1, 2])).palette()
+
+
+def test_rscheduler_vector_matrix_keys_and_bindings():
+    """row f-2: VECTOR / MATRIX keys (todo!() in the reference) and tracks bound to parts_disp / instance matrices"""
+    m0 = tuple(float(i) for i in range(16))
+    m1 = tuple(float(100 + i) for i in range(16))
+    tracks = [dict(type=1, name="root"),
+              dict(type=11, prop=files.PROP_BOOL, name="PartsDisp2", keys=[(0, 0, True), (10, 0, False)]),
+              dict(type=6, prop=files.PROP_U32, name="PartsDisp0", keys=[(5, 0, 0)]),
+              dict(type=16, prop=22, name="Inst1Matrix", keys=[(0, 0, m0), (20, 0, m1)]),
+              dict(type=8, prop=21, name="Inst0Pos", keys=[(0, 0, (1.0, 2.0, 3.0, 9.0)), (15, 0, (-1.0, -2.0, -3.0, 9.0))]),
+              dict(type=9, prop=files.PROP_F32, name="Inst2Y", keys=[(8, 0, 0.5)])]
+    sf = files.SchedulerFile(mt_files.write_rscheduler(tracks))
+    assert sf.find_track("Inst1Matrix") == 3 and sf.find_track("nope") is None
+    assert tuple(sf.key_floats(3, 1)) == m1 and tuple(sf.key_floats(4, 0)) == (1.0, 2.0, 3.0, 9.0) and tuple(sf.key_floats(5, 0)) == (0.5,)
+    assert tuple(sf.eval_floats(3, 19)) == m0 and tuple(sf.eval_floats(3, 20)) == m1
+    with pytest.raises(api.MtrError):
+        sf.key_floats(1, 0)  # a BOOL track has no float keys
+    T = files
+    bindings = [(1, T.SDL_PARTS_DISP, 2), (2, T.SDL_PARTS_DISP, 0), (3, T.SDL_INSTANCE_MATRIX, 1), (4, T.SDL_INSTANCE_TRANSLATION, 0),
+                (5, T.SDL_INSTANCE_TRANSLATE_Y, 2)]
+    for frame, want_pd, want_t0, want_y2, want_m1 in ((0, [1, 1, 1], (1, 2, 3), 0.0, m0), (7, [0, 1, 1], (1, 2, 3), 0.0, m0),
+                                                       (12, [0, 1, 0], (1, 2, 3), 0.5, m0), (25, [0, 1, 0], (-1, -2, -3), 0.5, m1)):
+        pd = np.ones(3, dtype=np.uint8)
+        mm = np.tile(np.eye(4, dtype=np.float32).reshape(16), (3, 1))
+        sf.apply(frame, bindings, pd, mm)
+        assert list(pd) == want_pd, frame
+        assert tuple(mm[0, 12:15]) == want_t0 and mm[0, 0] == 1.0 and mm[2, 13] == np.float32(want_y2) and tuple(mm[1]) == want_m1, frame
+    pd = np.ones(3, dtype=np.uint8)
+    mm = np.tile(np.eye(4, dtype=np.float32).reshape(16), (3, 1))
+    for bad in ([(3, T.SDL_PARTS_DISP, 0)], [(1, T.SDL_INSTANCE_MATRIX, 0)], [(4, T.SDL_INSTANCE_TRANSLATE_X, 0)], [(1, T.SDL_PARTS_DISP, 3)],
+                [(3, T.SDL_INSTANCE_MATRIX, 3)], [(99, T.SDL_PARTS_DISP, 0)], [(5, 17, 0)]):
+        with pytest.raises(api.MtrError):
+            sf.apply(0, bad, pd, mm)
+    sf.close()

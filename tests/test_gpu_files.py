@@ -111,3 +111,61 @@ def test_material_states_and_mip_chains_from_files(gpu_device):
     ref = render_oracle(64, 64, [dict(md=md, M=M)])
     got = render_gpu(gpu_device, 64, 64, [dict(md=md, M=M, make_model=make)])
     assert_same(got, ref, "states + mips from files")
+
+
+def _skeleton(jn):
+    """jn joints in a chain at exactly representable offsets; imat = inverse bind world matrix"""
+    offs = [(0.0, 0.03125 * (j % 7) - 0.0625, 0.015625 * j) for j in range(jn)]
+    lm, im, acc = [], [], np.zeros(3)
+    for o in offs:
+        acc = acc + np.array(o)
+        t = np.eye(4); t[:3, 3] = o
+        ti = np.eye(4); ti[:3, 3] = -acc
+        lm.append(scene.to_f32_colmajor(t)); im.append(scene.to_f32_colmajor(ti))
+    joints = [(j, (j - 1) if j else 255, offs[j]) for j in range(jn)]
+    return joints, np.stack(lm), np.stack(im)
+
+
+def test_bind_pose_palette_from_the_file_skins_like_no_palette_at_all(gpu_device):
+    """row f-3 KAT: the palette formed from lmats / imats in bind pose is the identity, so the skinned render is bit-identical
+    to the unskinned one; and the per-joint cubes of Model::render (src/model.rs:309-315) come out of the file's joint offsets"""
+    W, H = 320, 200
+    md = scene.mesh50k(rows=12, cols=20)
+    # rigid weights (255, 0, 0, 0): w_0 = 1 exactly, so an identity palette reproduces the position bit for bit (blended
+    # weights b/255 sum to 1 only up to rounding, and then neither does the skinned position)
+    vb = md.vertex_buf.reshape(-1, 24).copy()
+    vb[:, 20:24] = (255, 0, 0, 0)
+    md.vertex_buf = vb.reshape(-1)
+    joints, lm, im = _skeleton(64)
+    rmodel, rshader2, rmaterial, _ = mt_files.files_from_model_data(md)
+    names = [f"mat_{p}" for p in range(md.nprims)]
+    rmodel = mt_files.write_rmodel(md, [mt_files.handle_of("IATest0", low=p) for p in range(md.nprims)], names, list(range(md.nprims)),
+                                   joints=joints, lmats=lm, imats=im)
+    sh = files.Shader2File(rshader2)
+    mat = files.MaterialFile(rmaterial, sh)
+    mf = files.ModelFile(rmodel)
+    pal = mf.palette()
+    assert (pal == np.eye(4, dtype=np.float32).reshape(16)).all()
+    M = scene.to_f32_colmajor(scene.headline_transform(W, H))
+    model = files.model_from_files(gpu_device, mf, sh, mat, [])
+    out = {}
+    for key, p in (("skinned", pal), ("unskinned", None)):
+        model.set_palette(p)
+        fr = api.Frame(gpu_device, W, H); model.render(fr, M); fr.end()
+        out[key] = (fr.color(), fr.depth(), fr.stats()); fr.close()
+    assert (out["skinned"][0] == out["unskinned"][0]).all() and (out["skinned"][1].view(np.uint32) == out["unskinned"][1].view(np.uint32)).all()
+    assert_same(out["unskinned"], render_oracle(W, H, [dict(md=md, M=M, palette=None)]), "unskinned from files")
+    # joint cubes: scale 0.005 at offset * 0.01, after the model, through the overlay path
+    model.set_palette(scene.bone_palette())
+    cam = scene.to_f32_colmajor(scene.reference_view_proj(W, H) @ scene.mat_translate(-5.0, 0.0, 1.0 - 0.06))
+    fr = api.Frame(gpu_device, W, H); model.render(fr, cam, joints=True); fr.end()
+    got = (fr.color(), fr.depth(), fr.stats()); fr.close()
+    cubes = np.zeros((64, 16), dtype=np.float32)
+    for j, (_no, _parent, off) in enumerate(joints):
+        cubes[j, 0] = cubes[j, 5] = cubes[j, 10] = np.float32(0.005)
+        cubes[j, 12:15] = np.array(off, dtype=np.float32) * np.float32(0.01)
+        cubes[j, 15] = 1.0
+    ref = render_oracle(W, H, [dict(md=md, M=cam, palette=scene.bone_palette()), dict(md=md, vp=cam, overlay=cubes)])
+    assert_same(got, ref, "model + joint cubes")
+    assert got[2]["tris_in"] == md.input_triangles() + 64 * 12
+    model.close(); mat.close(); sh.close()
