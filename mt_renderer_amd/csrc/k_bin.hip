@@ -57,9 +57,10 @@ __global__ __launch_bounds__(256) void k_fill(FrameBuffers fb, uint32_t total_ch
     const ChunkInfo ci = fb.chunk_info[gid];
     for (uint32_t round = 0; round * 64 < ci.n; ++round) {
         const uint32_t j = round * 64 + lane;
-        const bool act = j < ci.n;
+        bool act = j < ci.n;
         RecHdr h = {0, 0, 0, 0};
         if (act) h = fb.rec_hdr[ci.base + j];
+        act = act && h.bx0 <= h.bx1;  // a hole left by a guard-clipped fan (k_geom.hip)
         emit_bins<false>(fb, h, act, gid, round, lane);
     }
 }

@@ -103,6 +103,23 @@ __device__ __forceinline__ VOut clip_lerp(const VOut& in, const VOut& out) {  //
     return r;
 }
 
+// guard-band planes (SPEC.md 5.3): 0: x <= 64 w, 1: x >= -64 w, 2: y <= 64 w, 3: y >= -64 w; inside: distance >= 0
+#define MTR_MAX_POLY 8
+__device__ __forceinline__ float guard_dist(const VOut& v, int plane) {
+    return plane == 0 ? fmaf(64.0f, v.w, -v.x) : plane == 1 ? fmaf(64.0f, v.w, v.x) : plane == 2 ? fmaf(64.0f, v.w, -v.y) : fmaf(64.0f, v.w, v.y);
+}
+__device__ __forceinline__ VOut plane_lerp(const VOut& in, const VOut& out, float din, float dout) {  // din >= 0 > dout
+    const float t = din / (din - dout);
+    VOut r;
+    r.x = fmaf(t, out.x - in.x, in.x);
+    r.y = fmaf(t, out.y - in.y, in.y);
+    r.z = fmaf(t, out.z - in.z, in.z);
+    r.w = fmaf(t, out.w - in.w, in.w);
+    r.u = fmaf(t, out.u - in.u, in.u);
+    r.v = fmaf(t, out.v - in.v, in.v);
+    return r;
+}
+
 __device__ __forceinline__ void compose_matrix(const GeomParams& P, uint32_t inst, float (&M)[16]) {
     if (P.model_mats) {
         const float* B = P.model_mats + (size_t)inst * 16;
@@ -192,38 +209,66 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     const PV& tc = odd ? v1 : me;
 
     Rec r0, r1;
-    uint32_t n_out = 0;
+    uint32_t n_out = 0;   // records held in r0 / r1
+    // guard-band clipping (SPEC.md 5.3): a polygon with a vertex the rasteriser cannot take (w <= 0, or beyond +-2^20 px)
+    // is clipped against |x| <= 64 w, |y| <= 64 w and may fan into up to six triangles; its lane keeps the polygon (in
+    // scratch) and writes the records in a second pass, once every lane's place in the chunk's run is known
+    VOut poly[MTR_MAX_POLY];
+    uint32_t n_poly = 0;
     const uint32_t f_and = ta.flags & tb.flags & tc.flags, f_or = ta.flags | tb.flags | tc.flags;
     tri = tri && (f_and & 1u);            // every vertex inside the bound slice (SPEC.md)
     tri = tri && ((f_and >> 2) == 0);     // trivial frustum reject
     if (tri) {
-        if (!((f_or >> 2) & OC_ZN)) {
+        if (!((f_or >> 2) & OC_ZN) && (f_and & 2u)) {
             if (setup_tri(ta, tb, tc, W, H, mat, pr.cull, r0)) n_out = 1;
         } else {
-            // near-plane clip (z >= 0): rare, re-shades the three vertices in clip space
+            // near-plane clip (z >= 0) and / or guard-band clip: rare, re-shades the three vertices in clip space
             const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
             VOut cv[3] = {shade_vertex(P.vbuf, pr, ia, M, s_pal, P.npal, skinned),
                           shade_vertex(P.vbuf, pr, ib, M, s_pal, P.npal, skinned),
                           shade_vertex(P.vbuf, pr, ic, M, s_pal, P.npal, skinned)};
-            VOut poly[4];
-            int n = 0;
+            int n = 3;
+            if ((f_or >> 2) & OC_ZN) {
+                n = 0;
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const VOut& pp = cv[i];
-                const VOut& qq = cv[(i + 1) % 3];
-                bool pin = !(pp.z < 0.0f), qin = !(qq.z < 0.0f);
-                if (pin) poly[n++] = pp;
-                if (pin != qin) poly[n++] = pin ? clip_lerp(pp, qq) : clip_lerp(qq, pp);
+                for (int i = 0; i < 3; i++) {
+                    const VOut& pp = cv[i];
+                    const VOut& qq = cv[(i + 1) % 3];
+                    bool pin = !(pp.z < 0.0f), qin = !(qq.z < 0.0f);
+                    if (pin) poly[n++] = pp;
+                    if (pin != qin) poly[n++] = pin ? clip_lerp(pp, qq) : clip_lerp(qq, pp);
+                }
+            } else {
+                poly[0] = cv[0]; poly[1] = cv[1]; poly[2] = cv[2];
             }
             if (n >= 3) {
-                PV q0 = project(poly[0], W, H), q1 = project(poly[1], W, H), q2 = project(poly[2], W, H);
-                bool s0 = setup_tri(q0, q1, q2, W, H, mat, pr.cull, r0);
-                bool s1 = false;
-                if (n == 4) {
-                    PV q3 = project(poly[3], W, H);
-                    s1 = setup_tri(q0, q2, q3, W, H, mat, pr.cull, s0 ? r1 : r0);
+                bool all_ok = true;
+                for (int i = 0; i < n; i++) all_ok = all_ok && (project(poly[i], W, H).flags & 2u);
+                if (all_ok) {
+                    PV q0 = project(poly[0], W, H), q1 = project(poly[1], W, H), q2 = project(poly[2], W, H);
+                    bool s0 = setup_tri(q0, q1, q2, W, H, mat, pr.cull, r0);
+                    bool s1 = false;
+                    if (n == 4) {
+                        PV q3 = project(poly[3], W, H);
+                        s1 = setup_tri(q0, q2, q3, W, H, mat, pr.cull, s0 ? r1 : r0);
+                    }
+                    n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
+                } else {
+                    VOut tmp[MTR_MAX_POLY];
+                    for (int plane = 0; plane < 4 && n >= 3; plane++) {
+                        int m = 0;
+                        for (int i = 0; i < n; i++) {
+                            const VOut pp = poly[i], qq = poly[(i + 1) % n];
+                            const float dp = guard_dist(pp, plane), dq = guard_dist(qq, plane);
+                            const bool pin = !(dp < 0.0f), qin = !(dq < 0.0f);
+                            if (pin && m < MTR_MAX_POLY) tmp[m++] = pp;
+                            if (pin != qin && m < MTR_MAX_POLY) tmp[m++] = pin ? plane_lerp(pp, qq, dp, dq) : plane_lerp(qq, pp, dq, dp);
+                        }
+                        for (int i = 0; i < m; i++) poly[i] = tmp[i];
+                        n = m;
+                    }
+                    if (n >= 3) n_poly = (uint32_t)n;
                 }
-                n_out = (s0 ? 1u : 0u) + (s1 ? 1u : 0u);
             }
         }
     }
@@ -237,11 +282,24 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
         n_out = (k0 ? 1u : 0u) + (k1 ? 1u : 0u);
     }
 
-    // ---- wave compaction: one contiguous, ordered run of records per chunk ----
+    // ---- wave compaction: one contiguous, ordered run of records per chunk.  A guard-clipped lane reserves a slot for
+    //      every triangle of its fan (a culled or empty one leaves a hole: an empty bin rectangle that nothing reads) ----
+    const uint32_t n_res = n_poly ? n_poly - 2u : n_out;
+    uint32_t rank, total;
     const uint64_t b1 = __ballot(n_out >= 1), b2 = __ballot(n_out == 2);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t rank = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
-    uint32_t total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    if (!__ballot(n_poly != 0)) {
+        const uint64_t lt = (1ull << lane) - 1ull;
+        rank = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
+        total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+    } else {
+        const uint32_t inc = wave_incl_scan_u32(n_res);
+        rank = inc - n_res;
+        total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        if (total > MTR_CHUNK_SLOTS) {  // the run has a fixed place and size: report, emit nothing (the host fails the frame)
+            if (lane == 0) atomicOr(&P.fb.counters[CTR_OVERFLOW], 1u);
+            total = 0;
+        }
+    }
     // the run lives at a fixed place (chunk id * MTR_CHUNK_SLOTS): no allocator, no hot counter
     const uint32_t base = gid * MTR_CHUNK_SLOTS;
     if (lane == 0) {
@@ -249,7 +307,8 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
             ChunkInfo ci = {base, total};
             P.fb.chunk_info[gid] = ci;
         }
-        if (total) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], total);  // statistics only
+        const uint32_t nrec = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+        if (total && nrec) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], nrec);  // statistics only
     }
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
@@ -259,23 +318,37 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     // a solid colour in the default depth state replaces the pixel whatever the blend (its alpha is 1): the fragment
     // stage finds the colour in the record itself, no dependent material lookup; everything else carries its material id
     const uint32_t solid = (dmat.shader != MTR_SH_TEXTURED && dmat.blend != MTR_DB_ADD && dmat.dstate == 3u) ? 1u : 0u;
-    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = solid | ((dmat.blend != MTR_DB_OFF ? 1u : 0u) << 8) | (dmat.translucent << 16);
-    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = r0.a.pad1;
-    if (n_out >= 1) {
-        const bool lg = rec_is_large(r0.a);
-        P.fb.rec_a[base + rank] = rec_pack(r0.a, lg);
-        if (lg) P.fb.rec_l[base + rank] = make_int4(r0.a.X1, r0.a.Y1, r0.a.X2, r0.a.Y2);
-        if (MODE == 0) P.fb.rec_hdr[base + rank] = r0.h;  // read back by k_fill only
-        if (want_b) P.fb.rec_b[base + rank] = r0.b;
-        s_hdr[rank] = r0.h;
-    }
-    if (n_out == 2) {
-        const bool lg = rec_is_large(r1.a);
-        P.fb.rec_a[base + rank + 1] = rec_pack(r1.a, lg);
-        if (lg) P.fb.rec_l[base + rank + 1] = make_int4(r1.a.X1, r1.a.Y1, r1.a.X2, r1.a.Y2);
-        if (MODE == 0) P.fb.rec_hdr[base + rank + 1] = r1.h;
-        if (want_b) P.fb.rec_b[base + rank + 1] = r1.b;
-        s_hdr[rank + 1] = r1.h;
+    const uint32_t mflags = solid | ((dmat.blend != MTR_DB_OFF ? 1u : 0u) << 8) | (dmat.translucent << 16);
+    r0.a.pad0 = dmat.rgba8; r0.a.pad1 = mflags;
+    r1.a.pad0 = dmat.rgba8; r1.a.pad1 = mflags;
+    auto put_rec = [&](uint32_t slot, const Rec& r) {
+        const bool lg = rec_is_large(r.a);
+        P.fb.rec_a[base + slot] = rec_pack(r.a, lg);
+        if (lg) P.fb.rec_l[base + slot] = make_int4(r.a.X1, r.a.Y1, r.a.X2, r.a.Y2);
+        if (MODE == 0) P.fb.rec_hdr[base + slot] = r.h;  // read back by k_fill only
+        if (want_b) P.fb.rec_b[base + slot] = r.b;
+        s_hdr[slot] = r.h;
+    };
+    if (n_out >= 1) put_rec(rank, r0);
+    if (n_out == 2) put_rec(rank + 1, r1);
+    if (n_poly) {  // the fan of a guard-clipped polygon: (p0, p_k+1, p_k+2)
+        uint32_t nvalid = 0;
+        for (uint32_t k = 0; k + 2u < n_poly; k++) {
+            Rec t;
+            const PV q0 = project(poly[0], W, H), q1 = project(poly[k + 1], W, H), q2 = project(poly[k + 2], W, H);
+            bool ok = setup_tri(q0, q1, q2, W, H, mat, pr.cull, t);
+            if (ok && P.fb.own.world > 1) ok = rect_owned_any(P.fb.own, t.h.bx0, t.h.by0, t.h.bx1, t.h.by1, P.fb.nbx);
+            if (ok) {
+                t.a.pad0 = dmat.rgba8; t.a.pad1 = mflags;
+                put_rec(rank + k, t);
+                nvalid++;
+            } else {
+                const RecHdr hole = {1, 1, 0, 0};  // bx0 > bx1: no bin
+                s_hdr[rank + k] = hole;
+                if (MODE == 0) P.fb.rec_hdr[base + rank + k] = hole;
+            }
+        }
+        if (nvalid) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid + lane)], nvalid);  // statistics only
     }
     // s_hdr is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -286,9 +359,10 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     //      otherwise count only (one non-returning atomic per (wave, bin) group), k_scan + k_fill follow ----
     for (uint32_t round = 0; round * 64 < total; ++round) {
         const uint32_t j = round * 64 + lane;
-        const bool act = j < total;
+        bool act = j < total;
         RecHdr h = {0, 0, 0, 0};
         if (act) h = s_hdr[j];
+        act = act && h.bx0 <= h.bx1;  // a hole left by a guard-clipped fan
         if (MODE == 2) {
             emit_bins_unordered(P.fb, h, act, gid, round, lane, s_slot);
         } else if (MODE == 1) {

@@ -1765,7 +1765,7 @@ static int32_t settle_frame(mtr_frame* f, bool wait_done) {
         }
         f->flags_checked = true;
         if (!flags) return MTR_OK;
-        if (flags & 1u) return fail(d, MTR_E_OVERFLOW, "record capacity exceeded (internal bound violated)");
+        if (flags & 1u) return fail(d, MTR_E_OVERFLOW, "a geometry chunk (62 strip positions) needed more than 124 records: guard-band clipping fanned too many of its triangles");
         if (!(flags & 4u)) {
             // exact queues too small: grow to what the scan measured
             uint32_t two[2] = {0, 0};

@@ -194,10 +194,24 @@ __device__ __forceinline__ bool rect_owned_any(const Ownership& o, uint32_t bx0,
     return false;
 }
 
+// wave-wide inclusive prefix sum: Hillis-Steele inside each row of 16 lanes with DPP row_shr (lanes shifted in from
+// outside the row read 0), then the totals of the rows below are added (three v_readlane).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = (threadIdx.x & 63u) >> 4;
+    return v + (row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2);
+}
+
 // counters[]: [1] entries, [2] segments (two-pass scan), [3] overflow flags, then CTR_NSHARDS statistics shards of one
 // 128-byte line each: {surviving triangles, (triangle, bin) pairs, segments}.  One line per shard: atomics that share
 // a line serialise in its L2 channel (64 shards packed into two lines cost k_geom 20 us on the headline scene).
-// CTR_OVERFLOW bits: 1 record capacity (impossible), 2 two-pass queue capacity, 4 direct-mode per-bin queue full
+// CTR_OVERFLOW bits: 1 a chunk needed more than MTR_CHUNK_SLOTS records (guard-band clipping fanning many triangles of
+// one chunk), 2 two-pass queue capacity, 4 direct-mode per-bin queue full
 enum { CTR_ENTRIES = 1, CTR_SEGS = 2, CTR_OVERFLOW = 3, CTR_SHARD_BASE = 32, CTR_SHARD_STRIDE = 32, CTR_NSHARDS = 128,
        CTR_REC = 0, CTR_ENT = 1, CTR_SEG = 2, CTR_CULL = 3 /* geometry chunks culled against the ownership map */,
        CTR_NUM = CTR_SHARD_BASE + CTR_NSHARDS * CTR_SHARD_STRIDE };

@@ -140,19 +140,6 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// wave-wide inclusive prefix sum: Hillis-Steele inside each row of 16 lanes with DPP row_shr (lanes shifted in from
-// outside the row read 0), then the totals of the rows below are added (three v_readlane).
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
-    const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
-    const uint32_t row = (threadIdx.x & 63u) >> 4;
-    return v + (row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2);
-}
-
 // XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous run of this rank's bins
 // (own_list is row-major for interleaved / band ownership and super-tile-major for super-tiles).
 // Returns false when this block has no bin.

@@ -632,9 +632,53 @@ static int setup_tri(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int cull
     return 1;
 }
 
-/* assembles up to two screen triangles from one clip-space triangle; returns the count */
-static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int cull, tri_setup out[2]) {
-    out[0].valid = out[1].valid = 0;
+/* Guard band (SPEC 5.3): the rasteriser works in 24.8 fixed point inside +-2^20 px.  A polygon with a vertex it cannot
+ * project (w <= 0, or beyond the band) is clipped against the four planes |x| <= 64 w, |y| <= 64 w -- 64 half-targets from
+ * the centre, inside the band for every target up to 16384 px -- in that order: +x, -x, +y, -y.  Same Sutherland-Hodgman
+ * step as the near plane: a is emitted if inside, then the intersection, always computed from the inside vertex towards
+ * the outside one with t = d_I / (d_I - d_O), d = the plane's signed distance, every attribute fma(t, O - I, I). */
+#define ORC_GUARD_K 64.0f
+#define ORC_MAX_POLY 8
+
+static float guard_dist(const cvert *v, int plane) {
+    switch (plane) {
+    case 0: return fmaf(ORC_GUARD_K, v->w, -v->x);  /* x <= 64 w */
+    case 1: return fmaf(ORC_GUARD_K, v->w, v->x);   /* x >= -64 w */
+    case 2: return fmaf(ORC_GUARD_K, v->w, -v->y);
+    default: return fmaf(ORC_GUARD_K, v->w, v->y);
+    }
+}
+
+static cvert plane_lerp(cvert in, cvert out, float din, float dout) { /* din >= 0 > dout */
+    float t = din / (din - dout);
+    cvert r;
+    r.x = fmaf(t, out.x - in.x, in.x);
+    r.y = fmaf(t, out.y - in.y, in.y);
+    r.z = fmaf(t, out.z - in.z, in.z);
+    r.w = fmaf(t, out.w - in.w, in.w);
+    r.u = fmaf(t, out.u - in.u, in.u);
+    r.v = fmaf(t, out.v - in.v, in.v);
+    return r;
+}
+
+static int clip_poly_plane(const cvert *in, int n, int plane, cvert *out) {
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        cvert p = in[i], q = in[(i + 1) % n];
+        float dp = guard_dist(&p, plane), dq = guard_dist(&q, plane);
+        int pin = !(dp < 0.0f), qin = !(dq < 0.0f);
+        if (pin && m < ORC_MAX_POLY) out[m++] = p;
+        if (pin != qin && m < ORC_MAX_POLY) out[m++] = pin ? plane_lerp(p, q, dp, dq) : plane_lerp(q, p, dq, dp);
+    }
+    return m;
+}
+
+static int projectable(cvert c, uint32_t W, uint32_t H) { return project(c, W, H).ok; }
+
+/* assembles the screen triangles of one clip-space triangle (at most ORC_MAX_POLY - 2); returns how many slots of out[]
+ * were used (a slot may hold an invalid set-up: culled or empty) */
+static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int cull, tri_setup out[ORC_MAX_POLY - 2]) {
+    for (int i = 0; i < ORC_MAX_POLY - 2; i++) out[i].valid = 0;
     /* trivial frustum reject; the WebGPU clip volume is -w<=x<=w, -w<=y<=w, 0<=z<=w */
     if (a.x < -a.w && b.x < -b.w && c.x < -c.w) return 0;
     if (a.x > a.w && b.x > b.w && c.x > c.w) return 0;
@@ -642,23 +686,32 @@ static int clip_and_setup(cvert a, cvert b, cvert c, uint32_t W, uint32_t H, int
     if (a.y > a.w && b.y > b.w && c.y > c.w) return 0;
     if (a.z < 0.0f && b.z < 0.0f && c.z < 0.0f) return 0;
     if (a.z > a.w && b.z > b.w && c.z > c.w) return 0;
-    if (!(a.z < 0.0f || b.z < 0.0f || c.z < 0.0f)) {
-        setup_tri(a, b, c, W, H, cull, &out[0]);
-        return 1;
+    cvert poly[ORC_MAX_POLY], tmp[ORC_MAX_POLY];
+    int n = 3;
+    poly[0] = a; poly[1] = b; poly[2] = c;
+    if (a.z < 0.0f || b.z < 0.0f || c.z < 0.0f) {
+        /* near-plane clip (z >= 0), Sutherland-Hodgman over the cycle a,b,c; intersections are always
+         * computed from the inside vertex towards the outside one so shared edges stay watertight */
+        cvert v[3] = {a, b, c};
+        n = 0;
+        for (int i = 0; i < 3; i++) {
+            cvert p = v[i], q = v[(i + 1) % 3];
+            int pin = !(p.z < 0.0f), qin = !(q.z < 0.0f);
+            if (pin) poly[n++] = p;
+            if (pin != qin) poly[n++] = pin ? clip_lerp(p, q) : clip_lerp(q, p);
+        }
+        if (n < 3) return 0;
     }
-    /* near-plane clip (z >= 0), Sutherland-Hodgman over the cycle a,b,c; intersections are always
-     * computed from the inside vertex towards the outside one so shared edges stay watertight */
-    cvert v[3] = {a, b, c}, poly[4];
-    int n = 0;
-    for (int i = 0; i < 3; i++) {
-        cvert p = v[i], q = v[(i + 1) % 3];
-        int pin = !(p.z < 0.0f), qin = !(q.z < 0.0f);
-        if (pin) poly[n++] = p;
-        if (pin != qin) poly[n++] = pin ? clip_lerp(p, q) : clip_lerp(q, p);
+    int all_ok = 1;
+    for (int i = 0; i < n; i++) all_ok = all_ok && projectable(poly[i], W, H);
+    if (!all_ok) { /* guard-band clip, only for polygons the rasteriser could not take as they are */
+        for (int plane = 0; plane < 4; plane++) {
+            n = clip_poly_plane(poly, n, plane, tmp);
+            memcpy(poly, tmp, sizeof(cvert) * (size_t)n);
+            if (n < 3) return 0;
+        }
     }
-    if (n < 3) return 0;
-    setup_tri(poly[0], poly[1], poly[2], W, H, cull, &out[0]);
-    if (n == 4) setup_tri(poly[0], poly[2], poly[3], W, H, cull, &out[1]);
+    for (int i = 0; i + 2 < n; i++) setup_tri(poly[0], poly[i + 1], poly[i + 2], W, H, cull, &out[i]);
     return n - 2;
 }
 
@@ -894,7 +947,14 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
         return ORC_E_UNSUPPORTED; /* src/rmodel.rs:215 from_repr().unwrap() */
     }
     f->tris_in += ntri;
-    tri_setup *su = (tri_setup *)malloc(sizeof(tri_setup) * 2 * (size_t)index_num);
+    /* two set-up slots per index position (near clipping yields at most two triangles); the rare position whose
+     * polygon went through the guard-band clip and fanned into more parks the rest in `ovf`, and only then is the array
+     * rebuilt with ORC_MAX_POLY - 2 slots per position */
+    size_t SPT = 2;
+    tri_setup *su = (tri_setup *)malloc(sizeof(tri_setup) * SPT * (size_t)index_num);
+    typedef struct { int64_t pos; int k; tri_setup s; } ovf_t;
+    ovf_t *ovf = NULL;
+    size_t novf = 0, capovf = 0;
     uint64_t nsetup = 0;
 #ifdef _OPENMP
 #pragma omp parallel for num_threads(nthreads) reduction(+ : nsetup) schedule(static)
@@ -907,13 +967,45 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
         /* a vertex outside the bound slice (src/model.rs:337-342): triangle dropped (SPEC.md) */
         if (vi[0] >= vc->vnum || vi[1] >= vc->vnum || vi[2] >= vc->vnum) continue;
         cvert a = shade_vertex(vc, vi[0]), b = shade_vertex(vc, vi[1]), c = shade_vertex(vc, vi[2]);
-        clip_and_setup(a, b, c, f->w, f->h, fs->cull, &su[2 * i]);
-        nsetup += (uint64_t)(su[2 * i].valid + su[2 * i + 1].valid);
+        tri_setup loc[ORC_MAX_POLY - 2];
+        clip_and_setup(a, b, c, f->w, f->h, fs->cull, loc);
+        su[2 * i] = loc[0];
+        su[2 * i + 1] = loc[1];
+        for (int k = 0; k < ORC_MAX_POLY - 2; k++) nsetup += (uint64_t)loc[k].valid;
+        for (int k = 2; k < ORC_MAX_POLY - 2; k++)
+            if (loc[k].valid) {
+#ifdef _OPENMP
+#pragma omp critical(orc_ovf)
+#endif
+                {
+                    if (novf == capovf) {
+                        capovf = capovf ? capovf * 2 : 64;
+                        ovf = (ovf_t *)realloc(ovf, capovf * sizeof(ovf_t));
+                    }
+                    ovf[novf].pos = i;
+                    ovf[novf].k = k;
+                    ovf[novf].s = loc[k];
+                    novf++;
+                }
+            }
     }
+    if (novf) {
+        const size_t S6 = ORC_MAX_POLY - 2;
+        tri_setup *su6 = (tri_setup *)calloc(S6 * (size_t)index_num, sizeof(tri_setup));
+        for (size_t i = 0; i < (size_t)index_num; i++) {
+            su6[S6 * i] = su[2 * i];
+            su6[S6 * i + 1] = su[2 * i + 1];
+        }
+        for (size_t j = 0; j < novf; j++) su6[S6 * (size_t)ovf[j].pos + (size_t)ovf[j].k] = ovf[j].s;
+        free(su);
+        su = su6;
+        SPT = S6;
+    }
+    free(ovf);
     f->tris_setup += nsetup;
     uint64_t frags = 0;
     if (nthreads <= 1) {
-        for (size_t i = 0; i < 2 * (size_t)index_num; i++)
+        for (size_t i = 0; i < SPT * (size_t)index_num; i++)
             if (su[i].valid) frags += raster_tri(f, &su[i], fs, 0, (int32_t)f->h);
     } else {
 #ifdef _OPENMP
@@ -922,7 +1014,7 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
          * the scalar path whatever the thread count */
         const int32_t BH = 8, nband = ((int32_t)f->h + BH - 1) / BH;
         uint32_t *bstart = (uint32_t *)calloc((size_t)nband + 1, sizeof(uint32_t));
-        for (size_t i = 0; i < 2 * (size_t)index_num; i++) {
+        for (size_t i = 0; i < SPT * (size_t)index_num; i++) {
             if (!su[i].valid) continue;
             int32_t ymin = su[i].Y[0], ymax = su[i].Y[0];
             for (int k = 1; k < 3; k++) {
@@ -937,7 +1029,7 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
         for (int32_t b = 0; b < nband; b++) bstart[b + 1] += bstart[b];
         uint32_t *blist = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)bstart[nband] + 1));
         uint32_t *bfill = (uint32_t *)calloc((size_t)nband, sizeof(uint32_t));
-        for (size_t i = 0; i < 2 * (size_t)index_num; i++) {
+        for (size_t i = 0; i < SPT * (size_t)index_num; i++) {
             if (!su[i].valid) continue;
             int32_t ymin = su[i].Y[0], ymax = su[i].Y[0];
             for (int k = 1; k < 3; k++) {
@@ -958,7 +1050,7 @@ static int draw_primitive(orc_frame *f, const vs_ctx *vc, const fs_state *fs, ui
         free(blist);
         free(bstart);
 #else
-        for (size_t i = 0; i < 2 * (size_t)index_num; i++)
+        for (size_t i = 0; i < SPT * (size_t)index_num; i++)
             if (su[i].valid) frags += raster_tri(f, &su[i], fs, 0, (int32_t)f->h);
 #endif
     }
