@@ -133,6 +133,14 @@ int32_t mtr_texture_create_mips(mtr_device *dev, uint32_t width, uint32_t height
 void mtr_texture_destroy(mtr_texture *tex);
 /* decoded RGBA8 texels of level 0 (row-major, width*height*4 bytes): what the sampler reads */
 int32_t mtr_texture_read_rgba8(mtr_texture *tex, void *out, size_t len);
+/* What a BC1 / BC7 texture created AFTER this call keeps in HBM.  The reference hands the blocks to the GPU's texture unit
+ * (device feature TEXTURE_COMPRESSION_BC, src/renderer_app_manager.rs:107); here either
+ *   MTR_TEXRES_DECODED  (default) the image is decoded to RGBA8 once at creation and the sampler reads plain texels, or
+ *   MTR_TEXRES_BLOCKS   the blocks stay as uploaded (1/4 of the bytes for BC7, 1/8 for BC1) and every fetch decodes its
+ *                       texel from its block.  Same pixels; mtr_texture_read_rgba8 returns MTR_E_UNSUPPORTED.
+ * DESIGN.md section 3 has the measured trade (C5: 64 textures of 1024 x 1024). */
+enum { MTR_TEXRES_DECODED = 0, MTR_TEXRES_BLOCKS = 1 };
+int32_t mtr_device_set_texture_residency(mtr_device *dev, uint32_t mode);
 
 /* ---- Model::new (src/model.rs:36-293) ----
  * vertex_buf/index_buf: ModelFile::vertex_buf()/index_buf() (src/rmodel.rs:457-463).

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_PKG, "libmtr.so")
 MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
 TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY, TILE_MIXED = 0, 1, 2, 3
 OWN_INTERLEAVED, OWN_BANDS, OWN_SUPERTILES = 0, 1, 2
+TEXRES_DECODED, TEXRES_BLOCKS = 0, 1
 STAGE_NAMES = ("geom", "scan", "fill", "tile")
 
 # every symbol include/mtr.h declares (tests check that the library exports each one)
@@ -36,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "mtr_model_vertex_stage", "mtr_crc32", "mtr_shard_bytes", "mtr_frame_pack_color_shard",
     "mtr_device_unpack_color_shards", "mtr_frame_read_bin_counts", "mtr_device_set_tile_mode", "mtr_device_set_binning",
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
-    "mtr_device_synchronize", "mtr_model_set_joint_positions", "mtr_frame_draw_model_joints", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
+    "mtr_device_synchronize", "mtr_model_set_joint_positions", "mtr_frame_draw_model_joints", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_device_set_texture_residency", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
     "mtr_frame_unpack_color_shards_on_stream", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
 ]
 
@@ -110,6 +111,7 @@ def _load() -> C.CDLL:
         "mtr_frame_set_shard": (i32, [vp, u32, u32]),
         "mtr_frame_set_shard_map": (i32, [vp, u32, u32, u32, u32, vp]),
         "mtr_device_set_culling": (i32, [vp, i32]),
+        "mtr_device_set_texture_residency": (i32, [vp, u32]),
         "mtr_shard_bytes_map": (sz, [u32, u32, u32, u32, u32, vp]),
         "mtr_frame_shard_bytes": (sz, [vp]),
         "mtr_frame_unpack_color_shards_on_stream": (i32, [vp, vp, vp, vp]),
@@ -220,6 +222,10 @@ class Device:
     def set_culling(self, on: bool):
         """sharded frames: skip geometry whose bounds cannot reach the rank's bins (default on)"""
         self.check(lib.mtr_device_set_culling(self._h, 1 if on else 0))
+
+    def set_texture_residency(self, mode: int):
+        """what BC textures created from now on keep in HBM: TEXRES_DECODED (RGBA8, default) or TEXRES_BLOCKS (include/mtr.h)"""
+        self.check(lib.mtr_device_set_texture_residency(self._h, mode))
 
     def set_tile_mode(self, mode: int):
         """0 auto, 1 force the ordered tile kernel, 2 visibility-key kernel when eligible (include/mtr.h)."""

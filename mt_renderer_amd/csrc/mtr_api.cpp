@@ -97,6 +97,7 @@ struct mtr_device {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool profiling = false;
+    uint32_t texture_residency = MTR_TEXRES_DECODED;
     int tile_mode = MTR_TILE_AUTO;
     std::string err;
     Slot slots[MTR_MAX_SLOTS];
@@ -177,7 +178,8 @@ struct mtr_texture {
     mtr_device* dev;
     uint32_t w, h, fmt;
     uint32_t levels = 1;  // mip levels in d_rgba, level 0 first
-    uint8_t* d_rgba;
+    uint8_t* d_rgba;          // decoded RGBA8 texels (MTR_TR_RGBA8) or the BC blocks as uploaded (MTR_TR_BC1 / MTR_TR_BC7)
+    uint32_t resident = MTR_TR_RGBA8;
     bool opaque;  // every decoded texel (of every level) has alpha == 255: sampling it yields a == 1 exactly
 };
 
@@ -831,39 +833,48 @@ int32_t mtr_texture_create_mips(mtr_device* d, uint32_t w, uint32_t h, uint32_t 
     if (rc) return rc;
     auto t = std::make_unique<mtr_texture>();
     t->dev = d; t->w = w; t->h = h; t->fmt = fmt; t->levels = levels; t->d_rgba = nullptr;
-    rc = dev_alloc(d, &t->d_rgba, texels * 4);
+    uint8_t* d_rgba = nullptr;    // the decoded image: the resident one, or (blocks resident) a temporary for the alpha scan
+    uint8_t* d_blocks = nullptr;
+    const bool keep_blocks = fmt != MTR_TEX_RGBA8 && d->texture_residency == MTR_TEXRES_BLOCKS;
+    rc = dev_alloc(d, &d_rgba, texels * 4);
     if (rc) return rc;
     if (fmt == MTR_TEX_RGBA8) {
-        HIPCHK(d, hipMemcpyAsync(t->d_rgba, data, need, hipMemcpyHostToDevice, d->stream));
+        HIPCHK(d, hipMemcpyAsync(d_rgba, data, need, hipMemcpyHostToDevice, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
     } else {
-        uint8_t* d_blocks = nullptr;
         rc = dev_alloc(d, &d_blocks, need);
-        if (rc) { (void)hipFree(t->d_rgba); return rc; }
+        if (rc) { (void)hipFree(d_rgba); return rc; }
         HIPCHK(d, hipMemcpyAsync(d_blocks, data, need, hipMemcpyHostToDevice, d->stream));
         size_t src_off = 0, dst_off = 0;
         for (uint32_t l = 0; l < levels; l++) {
             const uint32_t lw = std::max(1u, w >> l), lh = std::max(1u, h >> l);
-            if (fmt == MTR_TEX_BC1) mtr_launch_bc1_decode(d_blocks + src_off, t->d_rgba + dst_off, lw, lh, d->stream);
-            else mtr_launch_bc7_decode(d_blocks + src_off, t->d_rgba + dst_off, lw, lh, d->stream);
+            if (fmt == MTR_TEX_BC1) mtr_launch_bc1_decode(d_blocks + src_off, d_rgba + dst_off, lw, lh, d->stream);
+            else mtr_launch_bc7_decode(d_blocks + src_off, d_rgba + dst_off, lw, lh, d->stream);
             src_off += (size_t)((lw + 3) / 4) * ((lh + 3) / 4) * (fmt == MTR_TEX_BC1 ? 8 : 16);
             dst_off += (size_t)lw * lh * 4;
         }
         HIPCHK(d, hipGetLastError());
         HIPCHK(d, hipStreamSynchronize(d->stream));
-        (void)hipFree(d_blocks);
     }
     {
         uint32_t* d_min = nullptr;
         uint32_t h_min = 255;
         if ((rc = dev_alloc(d, &d_min, 1))) return rc;
         HIPCHK(d, hipMemcpyAsync(d_min, &h_min, 4, hipMemcpyHostToDevice, d->stream));
-        mtr_launch_alpha_min(t->d_rgba, texels, d_min, d->stream);
+        mtr_launch_alpha_min(d_rgba, texels, d_min, d->stream);
         HIPCHK(d, hipGetLastError());
         HIPCHK(d, hipMemcpyAsync(&h_min, d_min, 4, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
         (void)hipFree(d_min);
         t->opaque = h_min == 255;
+    }
+    if (keep_blocks) {  // the sampler decodes the texel's block per fetch (csrc/bc_sample.h): 1/4 (BC7) or 1/8 (BC1) of the bytes
+        (void)hipFree(d_rgba);
+        t->d_rgba = d_blocks;
+        t->resident = fmt == MTR_TEX_BC1 ? MTR_TR_BC1 : MTR_TR_BC7;
+    } else {
+        if (d_blocks) (void)hipFree(d_blocks);
+        t->d_rgba = d_rgba;
     }
     *out = t.release();
     return MTR_OK;
@@ -885,6 +896,7 @@ int32_t mtr_texture_read_rgba8(mtr_texture* t, void* out, size_t len) {
     if (!t || !out) return MTR_E_INVALID;
     mtr_device* d = t->dev;
     if (len < (size_t)t->w * t->h * 4) return fail(d, MTR_E_INVALID, "output too small");
+    if (t->resident != MTR_TR_RGBA8) return fail(d, MTR_E_UNSUPPORTED, "the texture is resident as BC blocks (mtr_device_set_texture_residency): there is no decoded image to read");
     int32_t rc = set_device(d);
     if (rc) return rc;
     HIPCHK(d, hipMemcpyAsync(out, t->d_rgba, (size_t)t->w * t->h * 4, hipMemcpyDeviceToHost, d->stream));
@@ -1263,6 +1275,13 @@ int32_t mtr_frame_set_shard(mtr_frame* f, uint32_t rank, uint32_t world) {
     return mtr_frame_set_shard_map(f, rank, world, MTR_OWN_INTERLEAVED, 0, nullptr);
 }
 
+int32_t mtr_device_set_texture_residency(mtr_device* d, uint32_t mode) {
+    if (!d) return MTR_E_INVALID;
+    if (mode != MTR_TEXRES_DECODED && mode != MTR_TEXRES_BLOCKS) return fail(d, MTR_E_INVALID, "unknown texture residency mode");
+    d->texture_residency = mode;
+    return MTR_OK;
+}
+
 int32_t mtr_device_set_culling(mtr_device* d, int32_t enable) {
     if (!d) return MTR_E_INVALID;
     d->cull_enabled = enable != 0;
@@ -1506,7 +1525,7 @@ static int32_t run_frame(mtr_frame* f) {
                     dm.shader = MTR_SH_TEXTURED;
                     const mtr_texture* t = m->textures[(size_t)tex];
                     if (!t->opaque && dm.blend == MTR_DB_ALPHA) order_dep = true;  // a texel with alpha < 255 really blends
-                    dm.tex = t->d_rgba; dm.tw = t->w; dm.th = t->h; dm.tlevels = t->levels;
+                    dm.tex = t->d_rgba; dm.tw = t->w; dm.th = t->h; dm.tlevels = t->levels | (t->resident << 8);
                 } else {
                     dm.shader = MTR_SH_DEBUG; dm.rgba8 = m->debug_rgba8[p];
                 }

@@ -73,10 +73,11 @@ struct DMat {            // one per (draw, [instance,] primitive)
     uint32_t tw, th;     // texture size
     uint32_t translucent;  // order-dependent: the pixel depends on the order of the fragments (a blend that is not a
                            // replace, depth write or depth test off): the ordered tile kernel's
-    const uint8_t* tex;  // decoded RGBA8 texels, mip levels one after the other
-    uint32_t tlevels;    // mip levels present (>= 1)
+    const uint8_t* tex;  // decoded RGBA8 texels (or, MTR_TR_BC*: the BC blocks), mip levels one after the other
+    uint32_t tlevels;    // mip levels present (>= 1) | MTR_TR_* << 8
     uint32_t dstate;     // bit0 depth write, bit1 depth test
 };
+enum { MTR_TR_RGBA8 = 0, MTR_TR_BC1 = 1, MTR_TR_BC7 = 2 };    // what DMat::tex holds (mtr_device_set_texture_residency)
 enum { MTR_DB_OFF = 0, MTR_DB_ALPHA = 1, MTR_DB_ADD = 2 };  // DMat::blend (0 / 1 as before the material states)
 
 struct RecHdr {          // 8 B: bins covered, inclusive
@@ -194,6 +195,7 @@ __device__ __forceinline__ bool rect_owned_any(const Ownership& o, uint32_t bx0,
     return false;
 }
 
+#ifdef __HIPCC__  // device only (the host sanitizer builds of tests/cpp include this header with g++)
 // wave-wide inclusive prefix sum: Hillis-Steele inside each row of 16 lanes with DPP row_shr (lanes shifted in from
 // outside the row read 0), then the totals of the rows below are added (three v_readlane).
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -206,6 +208,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     const uint32_t row = (threadIdx.x & 63u) >> 4;
     return v + (row == 0 ? 0u : row == 1 ? t0 : row == 2 ? t0 + t1 : t0 + t1 + t2);
 }
+#endif
 
 // counters[]: [1] entries, [2] segments (two-pass scan), [3] overflow flags, then CTR_NSHARDS statistics shards of one
 // 128-byte line each: {surviving triangles, (triangle, bin) pairs, segments}.  One line per shard: atomics that share

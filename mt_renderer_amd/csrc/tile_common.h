@@ -1,6 +1,7 @@
 // tile_common.h -- fragment-stage helpers shared by the ordered (k_tile.hip) and visibility
 // (k_tile_vis.hip) tile kernels.  Every formula is SPEC.md section 7, bit for bit.
 #pragma once
+#include "bc_sample.h"
 #include "mtr_internal.h"
 
 namespace mtr {
@@ -56,10 +57,26 @@ __device__ __forceinline__ int32_t clamp_texel(float f, uint32_t n) {
 struct TexRef {
     const uint8_t* tex;
     uint32_t tw, th;
-    uint32_t levels;  // mip levels present (the reference uploads one, src/texture.rs:21; more: row f-4)
+    uint32_t levels;  // DMat::tlevels: mip levels present (the reference uploads one, src/texture.rs:21; more: row f-4)
+                      // in the low byte, MTR_TR_* (what `tex` holds) above it
 };
+// one texel of mip level `level` (lw x lh) as RGBA8: from the image decoded at upload, or from the BC block it lives in
+__device__ __forceinline__ uint32_t texel_u32(const TexRef& m, int level, uint32_t lw, int32_t x, int32_t y) {
+    const uint32_t res = m.levels >> 8;
+    uint32_t w = m.tw, h = m.th;
+    size_t off = 0;
+    if (res == MTR_TR_RGBA8) {
+        for (int l = 0; l < level; l++) { off += (size_t)w * h; w = w > 1u ? w >> 1 : 1u; h = h > 1u ? h >> 1 : 1u; }
+        return reinterpret_cast<const uint32_t*>(m.tex)[off + (size_t)y * lw + (size_t)x];
+    }
+    for (int l = 0; l < level; l++) { off += (size_t)((w + 3u) >> 2) * ((h + 3u) >> 2); w = w > 1u ? w >> 1 : 1u; h = h > 1u ? h >> 1 : 1u; }
+    const size_t b = off + (size_t)((uint32_t)y >> 2) * ((lw + 3u) >> 2) + ((uint32_t)x >> 2);
+    const uint32_t i = ((uint32_t)y & 3u) * 4u + ((uint32_t)x & 3u);
+    if (res == MTR_TR_BC1) return bc1_texel(reinterpret_cast<const uint2*>(m.tex)[b], i);
+    return bc7_texel(reinterpret_cast<const ulonglong2*>(m.tex)[b], i);
+}
 __device__ __forceinline__ void texel_f(const TexRef& m, int32_t x, int32_t y, float (&o)[4]) {
-    uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[(size_t)y * m.tw + (size_t)x];
+    const uint32_t t = texel_u32(m, 0, m.tw, x, y);
     o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
 }
 
@@ -69,10 +86,9 @@ __device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v
     const float fw = (float)m.tw, fh = (float)m.th;
     if (flt >= 0) {
         uint32_t lw = m.tw, lh = m.th;
-        size_t off = 0;
-        for (int l = 0; l < flt; l++) { off += (size_t)lw * lh; lw = lw > 1u ? lw >> 1 : 1u; lh = lh > 1u ? lh >> 1 : 1u; }
+        for (int l = 0; l < flt; l++) { lw = lw > 1u ? lw >> 1 : 1u; lh = lh > 1u ? lh >> 1 : 1u; }
         const int32_t x = clamp_texel(floorf(u * (float)lw), lw), y = clamp_texel(floorf(v * (float)lh), lh);
-        const uint32_t t = reinterpret_cast<const uint32_t*>(m.tex)[off + (size_t)y * lw + (size_t)x];
+        const uint32_t t = texel_u32(m, flt, lw, x, y);
         o[0] = unorm8f(t); o[1] = unorm8f(t >> 8); o[2] = unorm8f(t >> 16); o[3] = unorm8f(t >> 24);
         return;
     }
@@ -94,6 +110,7 @@ __device__ __forceinline__ void sample_texture(const TexRef& m, float u, float v
 // SPEC.md section 7: -1 = linear (every derivative product <= 1: magnification), else the mip level of a nearest
 // sample: level l while m > 2^(l - 1/2), i.e. m * m > 2^(2l - 1), m = the largest product (NaN: level 0)
 __device__ __forceinline__ int filter_select(float dudx, float dvdx, float dudy, float dvdy, uint32_t tw, uint32_t th, uint32_t levels) {
+    levels &= 0xffu;  // DMat::tlevels carries MTR_TR_* above the count
     const float fw = (float)tw, fh = (float)th;
     const float a = fabsf(dudx) * fw, b = fabsf(dvdx) * fh, c = fabsf(dudy) * fw, d = fabsf(dvdy) * fh;
     if ((a <= 1.0f) && (b <= 1.0f) && (c <= 1.0f) && (d <= 1.0f)) return -1;
