@@ -41,6 +41,10 @@ class Device {
     void exchange_add_lane(void* comm, void* send_dev, void* gathered_dev, void* dst_dev, void* hip_stream) const {
         check(mtr_device_exchange_add_lane(h_, comm, send_dev, gathered_dev, dst_dev, hip_stream));
     }
+    // waits for every frame in flight; reports (once) an overflow latched by a frame nobody waited for
+    void synchronize() const { check(mtr_device_synchronize(h_)); }
+    void set_culling(bool on) const { check(mtr_device_set_culling(h_, on ? 1 : 0)); }  // sharded frames: per-rank geometry culling
+    void set_texture_residency(uint32_t mode) const { check(mtr_device_set_texture_residency(h_, mode)); }  // MTR_TEXRES_*
     void exchange_drain() const { check(mtr_device_exchange_drain(h_)); }
     void exchange_stop() const { check(mtr_device_exchange_stop(h_)); }
     void check(int32_t rc) const {
@@ -56,6 +60,10 @@ class Texture {
     // Texture::new(device, queue, resource) -- src/texture.rs:11
     Texture(const Device& dev, uint32_t width, uint32_t height, uint32_t format, const void* data, size_t len) {
         dev.check(mtr_texture_create(dev.handle(), width, height, format, data, len, &h_));
+    }
+    // the same with the file's mip chain (level 0 first); the reference uploads level 0 only (src/texture.rs:21)
+    Texture(const Device& dev, uint32_t width, uint32_t height, uint32_t format, uint32_t levels, const void* data, size_t len) {
+        dev.check(mtr_texture_create_mips(dev.handle(), width, height, format, levels, data, len, &h_));
     }
     Texture(Texture&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
     Texture(const Texture&) = delete;
@@ -90,6 +98,11 @@ class Model {
         dev_.check(mtr_model_set_parts_disp(h_, parts_disp.data(), parts_disp.size()));
     }
     void set_palette(const float* mats, size_t n) { dev_.check(mtr_model_set_palette(h_, mats, n)); }
+    // the state objects a material names (src/rmaterial.rs:211-230), applied per primitive; default = src/model.rs:240-262
+    void set_prim_states(const std::vector<mtr_prim_state>& states) { dev_.check(mtr_model_set_prim_states(h_, states.data(), states.size())); }
+    // joint positions for the per-joint debug cubes of Model::render (src/model.rs:309-315)
+    void set_joint_positions(const float* xyz, size_t njoints) { dev_.check(mtr_model_set_joint_positions(h_, xyz, njoints)); }
+    void render_with_joints(Frame& frame, const float view_proj[16]) const;
     // Model::render(&self, rpass, queue, transform_bind_group, debug_overlay) -- src/model.rs:299-305
     void render(Frame& frame, const float view_proj[16]) const;
     mtr_model* handle() const { return h_; }
@@ -113,6 +126,14 @@ class Frame {
     void wait() { dev_.check(mtr_frame_wait(h_)); }
     // multi-GPU: render only the bins with (bin % world) == rank, then pack them for the all-gather
     void set_shard(uint32_t rank, uint32_t world) { dev_.check(mtr_frame_set_shard(h_, rank, world)); }
+    // ownership map of a sharded frame: MTR_OWN_BANDS (band_rows: world + 1 bin rows or nullptr), MTR_OWN_SUPERTILES (param), ...
+    void set_shard_map(uint32_t rank, uint32_t world, uint32_t map, uint32_t param = 0, const uint32_t* band_rows = nullptr) {
+        dev_.check(mtr_frame_set_shard_map(h_, rank, world, map, param, band_rows));
+    }
+    size_t shard_bytes() const { return mtr_frame_shard_bytes(h_); }
+    void unpack_color_shards_on_stream(const void* gathered_dev, void* dst_dev, void* hip_stream) {
+        dev_.check(mtr_frame_unpack_color_shards_on_stream(h_, gathered_dev, dst_dev, hip_stream));
+    }
     void pack_color_shard(void* dst_dev, size_t dst_bytes) { dev_.check(mtr_frame_pack_color_shard(h_, dst_dev, dst_bytes)); }
     // hands the frame to the device's exchange thread, which owns (and destroys) it from here on
     void submit_exchange() {
@@ -138,6 +159,10 @@ class Frame {
 
 inline void Model::render(Frame& frame, const float view_proj[16]) const {
     dev_.check(mtr_frame_draw_model(frame.handle(), h_, view_proj));
+}
+
+inline void Model::render_with_joints(Frame& frame, const float view_proj[16]) const {
+    dev_.check(mtr_frame_draw_model_joints(frame.handle(), h_, view_proj));
 }
 
 // The reference's app seam (src/renderer_app_manager.rs:14-32), headless: the "frame_view + encoder" pair is the Frame.

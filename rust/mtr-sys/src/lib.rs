@@ -50,7 +50,25 @@ pub struct mtr_frame_stats {
     pub ndraws: u32,
     pub tile_kernel: u32,
     pub binning: u32,
+    pub chunks: u64,
+    pub chunks_culled: u64,
+    pub shard_map: u32,  // MTR_OWN_*
+    pub shard_bins: u32,
 }
+/// per-primitive material state (mtr.h): blend MTR_BLEND_*, depth write, depth test, cull MTR_CULL_*
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mtr_prim_state {
+    pub blend: u8,
+    pub depth_write: u8,
+    pub depth_test: u8,
+    pub cull: u8,
+}
+pub const MTR_OWN_INTERLEAVED: u32 = 0;
+pub const MTR_OWN_BANDS: u32 = 1;
+pub const MTR_OWN_SUPERTILES: u32 = 2;
+pub const MTR_TEXRES_DECODED: u32 = 0;
+pub const MTR_TEXRES_BLOCKS: u32 = 1;
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0] } )* } }
 opaque!(mtr_device, mtr_texture, mtr_model, mtr_batch, mtr_frame);
 
@@ -117,5 +135,19 @@ extern "C" {
     pub fn mtr_frame_destroy(frame: *mut mtr_frame);
     pub fn mtr_model_vertex_stage(model: *mut mtr_model, prim: usize, m: *const f32, out_clip: *mut f32, out_uv: *mut f32) -> i32;
     pub fn mtr_crc32(bytes: *const u8, len: usize, init: u32) -> u32;
+    // round 2
+    pub fn mtr_device_synchronize(dev: *mut mtr_device) -> i32;
+    pub fn mtr_device_set_culling(dev: *mut mtr_device, enable: i32) -> i32;
+    pub fn mtr_device_set_texture_residency(dev: *mut mtr_device, mode: u32) -> i32;
+    pub fn mtr_texture_create_mips(dev: *mut mtr_device, width: u32, height: u32, format: u32, levels: u32, data: *const c_void,
+                                   len: usize, out: *mut *mut mtr_texture) -> i32;
+    pub fn mtr_model_set_prim_states(model: *mut mtr_model, states: *const mtr_prim_state, nprims: usize) -> i32;
+    pub fn mtr_model_set_joint_positions(model: *mut mtr_model, xyz: *const f32, njoints: usize) -> i32;
+    pub fn mtr_frame_draw_model_joints(frame: *mut mtr_frame, model: *mut mtr_model, camera: *const f32) -> i32;
+    pub fn mtr_frame_set_shard_map(frame: *mut mtr_frame, rank: u32, world: u32, map: u32, param: u32, band_rows: *const u32) -> i32;
+    pub fn mtr_shard_bytes_map(width: u32, height: u32, world: u32, map: u32, param: u32, band_rows: *const u32) -> usize;
+    pub fn mtr_frame_shard_bytes(frame: *mut mtr_frame) -> usize;
+    pub fn mtr_frame_unpack_color_shards_on_stream(frame: *mut mtr_frame, gathered_dev: *const c_void, dst_dev: *mut c_void,
+                                                   hip_stream: *mut c_void) -> i32;
 }
 pub mod files;
