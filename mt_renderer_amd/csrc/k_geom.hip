@@ -406,22 +406,33 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
         return;
     }
-    // sharded: workgroup g takes group g / nsub of sub-list g % nsub of the work k_cull_chunks wrote (four chunks of one
-    // instance); the launch covers every sub-list's capacity and the workgroups past a sub-list's end leave at once.
-    // (Striding over the lists inside the kernel made the register allocator spill into the hot path: 249 us instead
-    // of 186 us for k_geom on C5 at N = 8, dead workgroups included.)
-    const uint32_t sub = blockIdx.x % P.work_nsub, gi = blockIdx.x / P.work_nsub;
-    if (gi * 4u >= P.work_counts[sub * MTR_CULL_CTR_STRIDE]) return;
-    const uint2* grp = P.work_list + (size_t)sub * P.work_sub_cap + gi * 4u;
-    const uint2 e = grp[wave];
-    const uint32_t inst = grp[0].y;  // the first entry of a group is never padding
+    // sharded: workgroup g = (group x, quarter q) fastest, then instance slot ii: it takes the q-th four survivors of the 16
+    // chunks of group x of instance slot ii, from the mask k_cull_chunks stored.  The launch covers every instance slot.
+    // Slots past the end of the instance list leave after one scalar load of its length (one address: a scalar-cache hit)
+    // and sit at the END of the launch, where they cost next to nothing -- 53 k instead of 262 k workgroups launched
+    // changed nothing.  Spread AMONG working workgroups they do cost: instance slot fastest-varying 213 us, a
+    // multiplicative walk over the slots 234 us, against 189 us for this order (C5, rank 3 of 8) -- the dispatcher
+    // hands out workgroups in order, and four that leave at once per one that works halve the rate at which work starts.
+    // (Fetching the group's 16 chunk descriptors together with the mask, lane = chunk, to take one load off the chain in
+    // front of the vertex work: 192 vs 189 us, no gain.)
+    const uint32_t nxq = P.work_nx * 4u, ii = blockIdx.x / nxq, xq = blockIdx.x - ii * nxq, x = xq >> 2, q = xq & 3u;
+    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    if (ii >= nlive) return;  // before touching anything else: a dead slot must cost no memory traffic
+    const uint32_t m16 = P.work_mask[(size_t)ii * P.work_nx + x];
+    const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
+    const uint32_t k = (uint32_t)__popc(m16);
+    if (q * 4u >= k) return;
     stage_palette(P, inst, s_pal);
-    if (e.x == 0xFFFFFFFFu) return;
-    const DChunk ch = P.chunks[e.x];
+    const uint32_t nth = q * 4u + wave;  // this wave's survivor
+    if (nth >= k) return;
+    uint32_t mm = m16;
+    for (uint32_t t = 0; t < nth; t++) mm &= mm - 1u;  // drop the nth lowest set bits (wave-uniform)
+    const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
+    const DChunk ch = P.chunks[c];
     const DPrim pr = P.prims[ch.prim];
     float M[16];
     compose_matrix(P, inst, M);
-    geom_chunk<MODE>(P, inst, e.x, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+    geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
 }
 
 __device__ __forceinline__ void compose_vp_model(const float (&vp)[16], const float* model_mats, uint32_t inst, float (&M)[16]) {
@@ -483,16 +494,16 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
 }
 
 // Chunk culling of a sharded draw.  256 threads = 16 rows of 16 lanes: row = one chunk, lane = one of its boxes; the
-// per-joint composites of the instance are built once per workgroup in LDS.  The chunks that may reach a bin of the
-// rank are appended to the work list in groups of four of the same instance (padded with 0xFFFFFFFF), which is what a
-// k_geom workgroup -- one palette in LDS, four waves -- consumes.  A light kernel (no records, no binning state) at
-// full occupancy: the test's chain of dependent loads is not paid inside k_geom's 80-register workgroups.
+// per-joint composites of the instance are built once per workgroup in LDS.  Which of the workgroup's 16 chunks may
+// reach a bin of the rank is stored as one 16-bit mask per (instance slot, group of 16 chunks): no list to append to,
+// no atomic; k_geom<.., true> launches four workgroups per mask, each taking four of its set bits (one palette in LDS,
+// four waves).  A light kernel (no records, no binning state) at full occupancy: the test's chain of dependent loads
+// is not paid inside k_geom's 80-register workgroups.
 template <bool LDS_COMP>  // true: the workgroup builds its instance's composites in LDS (a single model); false: they come from k_cull_instances
 __global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCullParams P) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     CompMat* s_comp = reinterpret_cast<CompMat*>(s_raw);
     __shared__ uint32_t s_wmask[4];
-    __shared__ uint32_t s_base;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane >> 4, sub = lane & 15u;
     const uint32_t c = blockIdx.x * 16u + wave * 4u + row;
     const bool has = c < P.nchunks;
@@ -537,20 +548,12 @@ __global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCull
         if (lane == 0)
             s_wmask[wave] = (uint32_t)(km & 1ull) | (uint32_t)((km >> 15) & 2ull) | (uint32_t)((km >> 30) & 4ull) | (uint32_t)((km >> 45) & 8ull);
         __syncthreads();
-        const uint32_t m16 = s_wmask[0] | (s_wmask[1] << 4) | (s_wmask[2] << 8) | (s_wmask[3] << 12);
-        const uint32_t k = (uint32_t)__popc(m16), k4 = (k + 3u) & ~3u;
-        const uint32_t sl = (blockIdx.x + ii) % P.work_nsub;
         if (threadIdx.x == 0) {
-            s_base = k ? sl * P.work_sub_cap + atomicAdd(&P.work_counts[sl * MTR_CULL_CTR_STRIDE], k4) : 0u;
+            const uint32_t m16 = s_wmask[0] | (s_wmask[1] << 4) | (s_wmask[2] << 8) | (s_wmask[3] << 12);
+            P.work_mask[(size_t)ii * gridDim.x + blockIdx.x] = (uint16_t)m16;
+            const uint32_t k = (uint32_t)__popc(m16);
             const uint32_t nhave = blockIdx.x * 16u < P.nchunks ? min(16u, P.nchunks - blockIdx.x * 16u) : 0u;
             if (nhave > k) atomicAdd(&P.fb.counters[MTR_CTR(CTR_CULL, blockIdx.x + inst)], nhave - k);  // statistics only
-        }
-        __syncthreads();
-        if (threadIdx.x < 16u) {
-            if ((m16 >> threadIdx.x) & 1u)
-                P.work_list[s_base + (uint32_t)__popc(m16 & ((1u << threadIdx.x) - 1u))] = make_uint2(blockIdx.x * 16u + threadIdx.x, inst);
-        } else if (threadIdx.x < 16u + (k4 - k)) {
-            P.work_list[s_base + k + (threadIdx.x - 16u)] = make_uint2(0xFFFFFFFFu, inst);
         }
     }
 }
@@ -577,9 +580,9 @@ __global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t pri
 void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     if (p.nchunks == 0 || p.ninst == 0) return;
     size_t lds = (size_t)p.npal * 64;
-    if (p.work_list) {
-        // sharded: one workgroup per group of every sub-list's capacity (the lengths are only known on the device)
-        dim3 grid(p.work_nsub * (p.work_sub_cap / 4));
+    if (p.work_mask) {
+        // sharded: four workgroups per group of 16 chunks and instance slot (what k_cull_chunks kept of them is on the device)
+        dim3 grid(p.work_nx * 4u * p.ninst);  // the host checked that this fits 31 bits
         if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
         else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);

@@ -63,9 +63,9 @@ struct Slot {
     uint32_t* inst_list = nullptr;   // sharded batch draws: compacted instance lists, draw after draw
     uint32_t* inst_count = nullptr;  // one counter per draw
     uint32_t inst_cap = 0, draw_cap = 0;
-    uint2* work_list = nullptr;      // sharded draws: the chunks that survive culling (k_cull_chunks -> k_geom), draw after draw
+    uint16_t* work_mask = nullptr;   // sharded draws: which chunks survive culling, one bit each (k_cull_chunks -> k_geom), draw after draw
     uint32_t work_cap = 0;
-    bool cull_counts_dirty = true;   // inst_count (MTR_CULL_CTR_WORDS per draw: instance-list length, work sub-list lengths) needs a fill
+    bool cull_counts_dirty = true;   // inst_count (MTR_CULL_CTR_WORDS per draw: word 0 = instance-list length) needs a fill
     uint32_t ctr_clean_draws = 0;    // draws whose counters the last tile kernel cleared
     CompMat* comp = nullptr;         // sharded batch draws: per (instance, joint) composites, k_cull_instances -> k_cull_chunks
     uint32_t comp_cap = 0;
@@ -766,7 +766,7 @@ void mtr_device_destroy(mtr_device* d) {
     }
     for (Slot& sl : d->slots) {
         void* ptrs[] = {sl.rec_hdr, sl.rec_a, sl.rec_l, sl.rec_b, sl.chunk_info, sl.bin_count, sl.bin_fill,
-                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count, sl.work_list, sl.comp};
+                        sl.bin_start, sl.seg_start, sl.entries, sl.segs, sl.mats, sl.bin_flag, sl.inst_list, sl.inst_count, sl.work_mask, sl.comp};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1592,22 +1592,18 @@ static int32_t run_frame(mtr_frame* f) {
     // sharded draws: k_cull_instances compacts the instance list of a batch draw to the instances that may reach this
     // rank's bins, k_cull_chunks then bounds every chunk of the surviving instances and writes the work list of k_geom
     const size_t ndraws = f->draws.size();
-    std::vector<uint32_t> inst_off(ndraws, 0xFFFFFFFFu), work_off(ndraws, 0u), comp_off(ndraws, 0u), nsub(ndraws, 1u), sub_cap(ndraws, 0u);
+    std::vector<uint32_t> inst_off(ndraws, 0xFFFFFFFFu), work_off(ndraws, 0u), comp_off(ndraws, 0u);
     if (fb.own.cull) {
         uint64_t ninst_total = 0, work_total = 0, comp_total = 0;
         for (size_t di = 0; di < ndraws; di++) {
             const Draw& dr = f->draws[di];
             const mtr_model* m = dr.model;
             const bool sk = dr.d_palettes && dr.npal;
-            // a cull workgroup (16 chunks) of instance slot ii appends to sub-list (x + ii) % nsub: <= ceil(nx / nsub) of
-            // them per instance slot and sub-list, 16 entries each at most
+            // one 16-bit mask per (instance slot, group of 16 chunks)
             const uint64_t nx = ((uint64_t)m->chunks.size() + 15) / 16;
-            nsub[di] = (uint32_t)std::min<uint64_t>(MTR_CULL_MAX_SUB, std::max<uint64_t>(nx, 1));
-            const uint64_t cap = (nx + nsub[di] - 1) / nsub[di] * 16 * dr.ninst;
-            if (cap > 0x7FFFFFF0ull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
-            sub_cap[di] = (uint32_t)cap;
+            if (nx * 4 * dr.ninst > 0x7FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
             work_off[di] = (uint32_t)work_total;
-            work_total += cap * nsub[di];
+            work_total += nx * dr.ninst;
             if (!dr.d_model_mats) continue;  // a single model: chunk culling only
             if (sk ? (!m->inst_skinned_boundable || m->n_inst_skinned == 0) : (m->n_inst_unskinned == 0)) continue;
             inst_off[di] = (uint32_t)ninst_total;
@@ -1620,9 +1616,9 @@ static int32_t run_frame(mtr_frame* f) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
             if ((rc = dev_grow(d, &sl.comp, &sl.comp_cap, std::max<uint64_t>(comp_total, 64)))) return rc;
         }
-        if (work_total > sl.work_cap || !sl.work_list) {
+        if (work_total > sl.work_cap || !sl.work_mask) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
-            if ((rc = dev_grow(d, &sl.work_list, &sl.work_cap, work_total))) return rc;
+            if ((rc = dev_grow(d, &sl.work_mask, &sl.work_cap, std::max<uint64_t>(work_total, 64)))) return rc;
         }
         if (ninst_total > sl.inst_cap || !sl.inst_list) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
@@ -1687,11 +1683,11 @@ static int32_t run_frame(mtr_frame* f) {
             memcpy(cc.vp, dr.vp, sizeof cc.vp);
             cc.fb = fb;
             cc.comp = inst_cnt ? sl.comp + comp_off[di] : nullptr;
-            cc.work_list = sl.work_list + work_off[di]; cc.work_counts = sl.inst_count + di * MTR_CULL_CTR_WORDS + MTR_CULL_CTR_STRIDE;
-            cc.work_nsub = nsub[di]; cc.work_sub_cap = sub_cap[di];
+            cc.work_mask = sl.work_mask + work_off[di];
             cc.keep_all = fb.own.cull == 3u ? 1u : 0u;
             mtr_launch_cull_chunks(cc, sg);
-            gp.work_list = cc.work_list; gp.work_counts = cc.work_counts; gp.work_nsub = cc.work_nsub; gp.work_sub_cap = cc.work_sub_cap;
+            gp.work_mask = cc.work_mask; gp.work_nx = (gp.nchunks + 15u) / 16u;
+            gp.inst_list = cc.inst_list; gp.inst_count = cc.inst_count;
         }
         mtr_launch_geom(gp, sg);
         chunk_base += gp.nchunks * dr.ninst;

@@ -53,9 +53,7 @@ struct BoneBox {
     uint32_t pad;
 };
 #define MTR_BOX_UNSKINNED 0xFFFFFFFFu
-#define MTR_CULL_MAX_SUB 64      // sub-lists of a draw's work list
-#define MTR_CULL_CTR_STRIDE 32   // words between two sub-list counters
-#define MTR_CULL_CTR_WORDS (MTR_CULL_CTR_STRIDE * (MTR_CULL_MAX_SUB + 1))  // per draw: word 0 = instance-list length, then the sub-list counters
+#define MTR_CULL_CTR_WORDS 32    // per draw (one 128-byte line): word 0 = instance-list length
 #define MTR_CHUNK_MAX_BOXES 15  // + the whole-chunk box = one row of 16 lanes
 
 // What the chunk test needs of one joint, per frame and instance: the clip rows x, y, w of C = M * [P_j; 0 0 0 1] and of
@@ -276,13 +274,16 @@ struct GeomParams {
     const BoneBox* boxes;     // chunk bounds (DChunk::b_first indexes it), nullptr: no culling data
     uint32_t nchunks;
     uint32_t ninst;           // instances of the draw
-    // sharded draws (k_geom<MODE, true>): the work k_cull_chunks wrote -- groups of four (chunk, instance) pairs of ONE
-    // instance, chunk 0xFFFFFFFF = padding -- in work_nsub sub-lists of work_sub_cap entries each, sub-list s filled up to
-    // work_counts[s * MTR_CULL_CTR_STRIDE] (one counter per 128-byte line: appends to one address serialise at ~10 ns
-    // each, which cost 312 us of a C5 frame at N = 2 with a single list).  Workgroup g takes group g / nsub of sub-list g % nsub.
-    const uint2* work_list;
-    const uint32_t* work_counts;
-    uint32_t work_nsub, work_sub_cap;
+    // sharded draws (k_geom<MODE, true>): what k_cull_chunks decided -- for instance slot ii (the ii-th entry of the
+    // compacted instance list, or instance ii itself when there is none) and group x of 16 consecutive chunks, bit b of
+    // work_mask[ii * work_nx + x] says chunk 16 x + b may reach a bin of this rank.  No list, no counter: a cull
+    // workgroup stores its mask, geometry workgroup (x, quarter q, ii) takes the q-th four set bits.  (Round 2 first
+    // appended the survivors to 64 sub-lists: one returning atomic per cull workgroup, one more dependent load in front
+    // of every geometry workgroup.)
+    const uint16_t* work_mask;
+    uint32_t work_nx;          // groups of 16 chunks per instance = ceil(nchunks / 16)
+    const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instance slot ii is instance ii
+    const uint32_t* inst_count;  // length of inst_list (device), or nullptr: ninst
     const float* model_mats;  // ninst*16 or nullptr
     const float* palettes;    // per instance npal*16 floats (stride pal_stride floats) or nullptr
     uint32_t npal, pal_stride;
@@ -364,9 +365,7 @@ struct ChunkCullParams {
     FrameBuffers fb;             // W, H, nbx, nby, own, counters
     const CompMat* comp;         // per-joint composites of every surviving instance (k_cull_instances), or nullptr: the
                                  // workgroup builds its instance's composites in LDS (a single model)
-    uint2* work_list;            // see GeomParams
-    uint32_t* work_counts;
-    uint32_t work_nsub, work_sub_cap;
+    uint16_t* work_mask;         // see GeomParams
     uint32_t keep_all;           // timing ablation (MTR_CULL_DEBUG=3): run the tests, keep everything
 };
 void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t s);
