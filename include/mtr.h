@@ -89,7 +89,7 @@ typedef struct mtr_frame_stats {
     uint32_t binning;     /* 1 = single-pass bounded queues, 2 = exact two-pass (count, scan, fill) queues */
     uint64_t chunks;        /* geometry waves of the frame (62 strip positions each, per instance) */
     uint64_t chunks_culled; /* of those, skipped by this rank before any vertex work: bounds outside its bins (sharded frames;
-                             * the chunks of instances culled as a whole are not counted) */
+                             * whole instances of a batch and single chunks alike) */
     uint32_t shard_map;     /* MTR_OWN_* */
     uint32_t shard_bins;    /* bins this rank rendered */
 } mtr_frame_stats;

@@ -327,6 +327,22 @@ __device__ __forceinline__ bool clipbox_may_touch_rank(const ClipBox& u, const F
     return rect_owned_any(fb.own, min(bx0, fb.nbx - 1u), min(by0, fb.nby - 1u), bx1, by1, fb.nbx);
 }
 
+// Is every bin that geometry with clip coordinates in `u` can produce a fragment in a bin of this rank?  (Then no part of
+// it needs testing against the rank's border.)  Same rectangle as clipbox_may_touch_rank; false whenever in doubt.
+__device__ __forceinline__ bool clipbox_all_in_rank(const ClipBox& u, const FrameBuffers& fb) {
+    const float ylo = u.lo[1], yhi = u.hi[1], wlo = u.lo[2], whi = u.hi[2];
+    if (!(wlo > 0.0f)) return false;
+    const float sy_lo = ylo >= 0.0f ? ylo / whi : ylo / wlo, sy_hi = yhi >= 0.0f ? yhi / wlo : yhi / whi;
+    const float fH = (float)fb.H, hh = 0.5f * fH;
+    float fy_lo = hh - sy_hi * hh, fy_hi = hh - sy_lo * hh;
+    const float my = 1.0f + 9.5367431640625e-07f * fmaxf(fabsf(fy_lo), fabsf(fy_hi));
+    fy_lo -= my; fy_hi += my;
+    if (!(fy_lo == fy_lo && fy_hi == fy_hi)) return false;
+    const uint32_t by0 = (uint32_t)fminf(fmaxf(fy_lo, 0.0f), fH) >> MTR_BIN_SHIFT;
+    const uint32_t by1 = min((uint32_t)fminf(fmaxf(fy_hi, 0.0f), fH) >> MTR_BIN_SHIFT, fb.nby - 1u);
+    return rect_owned_all(fb.own, min(by0, fb.nby - 1u), by1);
+}
+
 // wave-wide union of the lanes' intervals (lanes that hold none pass lo = +inf, hi = -inf); every lane gets the result
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll

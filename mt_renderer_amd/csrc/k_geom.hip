@@ -476,17 +476,31 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
 #pragma unroll
         for (int t = 0; t < 3; t++) { cb.lo[t] = fminf(cb.lo[t], one.lo[t]); cb.hi[t] = fmaxf(cb.hi[t], one.hi[t]); }
     }
-    bool keep = true;
+    bool keep = true, inside = false;
     if (!__ballot(bad) && P.nboxes) {
         ClipBox u;
 #pragma unroll
         for (int t = 0; t < 3; t++) { u.lo[t] = wave_min_f32(cb.lo[t]); u.hi[t] = wave_max_f32(cb.hi[t]); }
         FrameBuffers fb = {};
         fb.W = P.W; fb.H = P.H; fb.nbx = P.nbx; fb.nby = P.nby; fb.own = P.own;
-        keep = clipbox_may_touch_rank(u, fb);
+        keep = clipbox_may_touch_rank(u, fb) || P.own.cull >= 3u;  // 3, 4: timing ablations (MTR_CULL_DEBUG), keep everything
+        inside = (keep && clipbox_all_in_rank(u, fb)) || P.own.cull == 4u;
     }
-    if (!keep) return;
-    if (lane == 0) P.list[atomicAdd(P.count, 1u)] = inst;
+    if (!keep) {
+        if (lane == 0) atomicAdd(&P.counters[MTR_CTR(CTR_CULL, inst)], P.nchunks);  // statistics only
+        return;
+    }
+    uint32_t slot = 0;
+    if (lane == 0) {
+        slot = atomicAdd(P.count, 1u);
+        P.list[slot] = inst;
+        if (!inside) P.strad[atomicAdd(P.count + 1, 1u)] = slot;
+    }
+    if (inside) {  // every chunk of it is this rank's: no chunk tests (k_cull_chunks skips the slot)
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        const uint32_t nx = (P.nchunks + 15u) / 16u, tail = P.nchunks & 15u;
+        for (uint32_t x = lane; x < nx; x += 64) P.work_mask[(size_t)slot * nx + x] = (uint16_t)((x == nx - 1u && tail) ? (1u << tail) - 1u : 0xFFFFu);
+    }
     if (P.comp) {  // what the chunk tests of this instance read (k_cull_chunks)
         CompMat* out = P.comp + (size_t)inst * P.ncomp;
         for (uint32_t j = lane; j < P.ncomp; j += 64) out[j] = make_comp((have_pal && j + 1 < P.ncomp) ? pal + (size_t)j * 16 : nullptr, M);
@@ -518,8 +532,9 @@ __global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCull
     BoneBox bx = {};
     const bool tests = has && !unbounded && sub < n;
     if (tests) bx = P.boxes[first + sub];
-    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
-    for (uint32_t ii = blockIdx.y; ii < nlive; ii += gridDim.y) {
+    const uint32_t nlive = P.strad ? P.inst_count[1] : (P.inst_count ? *P.inst_count : P.ninst);
+    for (uint32_t si = blockIdx.y; si < nlive; si += gridDim.y) {
+        const uint32_t ii = P.strad ? P.strad[si] : si;  // the instance's slot: where its masks go
         const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
         __syncthreads();  // the composites and masks of the previous instance are no longer read
         if (LDS_COMP) {

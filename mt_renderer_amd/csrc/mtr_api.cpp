@@ -1593,6 +1593,7 @@ static int32_t run_frame(mtr_frame* f) {
     // rank's bins, k_cull_chunks then bounds every chunk of the surviving instances and writes the work list of k_geom
     const size_t ndraws = f->draws.size();
     std::vector<uint32_t> inst_off(ndraws, 0xFFFFFFFFu), work_off(ndraws, 0u), comp_off(ndraws, 0u);
+    uint32_t strad_base = 0;
     if (fb.own.cull) {
         uint64_t ninst_total = 0, work_total = 0, comp_total = 0;
         for (size_t di = 0; di < ndraws; di++) {
@@ -1620,9 +1621,10 @@ static int32_t run_frame(mtr_frame* f) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
             if ((rc = dev_grow(d, &sl.work_mask, &sl.work_cap, std::max<uint64_t>(work_total, 64)))) return rc;
         }
-        if (ninst_total > sl.inst_cap || !sl.inst_list) {
+        strad_base = (uint32_t)ninst_total;  // the second half of inst_list: the slots of the instances that straddle the rank's border
+        if (2 * ninst_total > sl.inst_cap || !sl.inst_list) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
-            if ((rc = dev_grow(d, &sl.inst_list, &sl.inst_cap, std::max<uint64_t>(ninst_total, 64)))) return rc;
+            if ((rc = dev_grow(d, &sl.inst_list, &sl.inst_cap, std::max<uint64_t>(2 * ninst_total, 64)))) return rc;
         }
         if (ndraws > sl.draw_cap || !sl.inst_count) {
             HIPCHK(d, hipStreamSynchronize(sl.stream));
@@ -1674,17 +1676,20 @@ static int32_t run_frame(mtr_frame* f) {
                 cp.W = f->w; cp.H = f->h; cp.nbx = nbx; cp.nby = nby; cp.own = fb.own;
                 cp.list = sl.inst_list + inst_off[di]; cp.count = inst_cnt = sl.inst_count + di * MTR_CULL_CTR_WORDS;
                 cp.comp = sl.comp + comp_off[di]; cp.ncomp = sk ? dr.npal + 1u : 1u;
+                cp.work_mask = sl.work_mask + work_off[di]; cp.strad = sl.inst_list + strad_base + inst_off[di]; cp.nchunks = gp.nchunks;
+                cp.counters = fb.counters;
                 mtr_launch_cull_instances(cp, sg);
             }
             ChunkCullParams cc{};
             cc.chunks = m->d_chunks; cc.boxes = m->d_boxes; cc.nchunks = gp.nchunks; cc.ninst = dr.ninst;
             cc.inst_list = inst_cnt ? sl.inst_list + inst_off[di] : nullptr; cc.inst_count = inst_cnt;
+            cc.strad = inst_cnt ? sl.inst_list + strad_base + inst_off[di] : nullptr;
             cc.model_mats = dr.d_model_mats; cc.palettes = gp.palettes; cc.npal = gp.npal; cc.pal_stride = gp.pal_stride;
             memcpy(cc.vp, dr.vp, sizeof cc.vp);
             cc.fb = fb;
             cc.comp = inst_cnt ? sl.comp + comp_off[di] : nullptr;
             cc.work_mask = sl.work_mask + work_off[di];
-            cc.keep_all = fb.own.cull == 3u ? 1u : 0u;
+            cc.keep_all = fb.own.cull >= 3u ? 1u : 0u;
             mtr_launch_cull_chunks(cc, sg);
             gp.work_mask = cc.work_mask; gp.work_nx = (gp.nchunks + 15u) / 16u;
             gp.inst_list = cc.inst_list; gp.inst_count = cc.inst_count;

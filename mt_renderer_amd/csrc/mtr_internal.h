@@ -175,6 +175,12 @@ __device__ __forceinline__ bool bin_owned(const Ownership& o, uint32_t bx, uint3
     return (by * nbx + bx) % o.world == o.rank;
 }
 
+// true only if EVERY bin of the inclusive rectangle belongs to the rank (bands; the other maps never say so)
+__device__ __forceinline__ bool rect_owned_all(const Ownership& o, uint32_t by0, uint32_t by1) {
+    if (o.world <= 1) return true;
+    return o.map == MTR_OWN_BANDS && by0 >= o.y0 && by1 < o.y1;
+}
+
 // true if some bin of the inclusive rectangle belongs to the rank; may say true for a rectangle that holds none (the
 // binner filters bin by bin), never false for one that does
 __device__ __forceinline__ bool rect_owned_any(const Ownership& o, uint32_t bx0, uint32_t by0, uint32_t bx1, uint32_t by1, uint32_t nbx) {
@@ -348,6 +354,13 @@ struct CullParams {
     uint32_t* count;
     CompMat* comp;             // out, for the surviving instances: their per-joint composites (ncomp each, indexed by instance)
     uint32_t ncomp;            // npal + 1 (skinned) or 1
+    // An instance whose whole screen rectangle lies in bins of this rank needs no chunk tests: its masks (GeomParams::
+    // work_mask, indexed by its slot in `list`) are written here, all ones.  The others -- the instances that straddle
+    // the rank's border -- are appended (by slot) to `strad`, length count[1], for k_cull_chunks.
+    uint16_t* work_mask;
+    uint32_t* strad;
+    uint32_t nchunks;
+    uint32_t* counters;        // the frame's counter block: the chunks of a culled instance are added to the CTR_CULL statistic
 };
 void mtr_launch_cull_instances(const CullParams& p, hipStream_t s);
 // chunk culling of a sharded draw: every chunk of every (surviving) instance is bounded against the rank's bins; the
@@ -358,6 +371,7 @@ struct ChunkCullParams {
     uint32_t nchunks, ninst;
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instances 0 .. ninst-1
     const uint32_t* inst_count;
+    const uint32_t* strad;       // slots (indices into inst_list) of the instances to test, length inst_count[1]; nullptr: every slot
     const float* model_mats;
     const float* palettes;
     uint32_t npal, pal_stride;

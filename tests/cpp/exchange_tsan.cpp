@@ -21,7 +21,7 @@ void mtr_launch_bc7_decode(const uint8_t*, uint8_t*, uint32_t, uint32_t, hipStre
 // the copies the real kernels make, so that the send / gathered / destination buffers are really written by this thread
 void mtr_launch_pack_shard(const uint8_t* color, uint8_t* dst, uint32_t, uint32_t, const uint32_t* own_list, uint32_t n, uint32_t, hipStream_t) { dst[0] = color[0] + (n ? (uint8_t)own_list[0] : 0); }
 void mtr_launch_unpack_shards(const uint8_t* g, uint8_t* dst, uint32_t, uint32_t, const uint32_t* src_of_bin, hipStream_t) { dst[0] = g[0] + (uint8_t)src_of_bin[0]; }
-void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) p.list[(*p.count)++] = i; }
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) { p.strad[p.count[1]++] = *p.count; p.list[(*p.count)++] = i; } }
 void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t) { if (p.nchunks && p.ninst) p.work_mask[(size_t)((p.nchunks + 15) / 16) * p.ninst - 1] = 0xFFFF; }  // the last mask of the draw
 
 static std::atomic<long> g_calls{0};

@@ -27,7 +27,7 @@ void mtr_launch_bc7_decode(const uint8_t* b, uint8_t* rgba, uint32_t w, uint32_t
 }
 void mtr_launch_pack_shard(const uint8_t*, uint8_t*, uint32_t, uint32_t, const uint32_t*, uint32_t, uint32_t, hipStream_t) {}
 void mtr_launch_unpack_shards(const uint8_t*, uint8_t*, uint32_t, uint32_t, const uint32_t*, hipStream_t) {}
-void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) p.list[(*p.count)++] = i; }
+void mtr_launch_cull_instances(const CullParams& p, hipStream_t) { for (uint32_t i = 0; i < p.ninst; i++) { p.strad[p.count[1]++] = *p.count; p.list[(*p.count)++] = i; } }
 void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t) { if (p.nchunks && p.ninst) p.work_mask[(size_t)((p.nchunks + 15) / 16) * p.ninst - 1] = 0xFFFF; }  // the last mask of the draw
 
 static uint64_t rs = 0x243F6A8885A308D3ull;
