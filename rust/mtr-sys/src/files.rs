@@ -139,4 +139,25 @@ extern "C" {
     pub fn mtr_rarchive_extract(a: *const mtr_rarchive_view, i: u32, out: *mut c_void, cap: usize, out_len: *mut usize) -> i32;
     pub fn mtr_model_create_from_files(dev: *mut mtr_device, model: *const mtr_rmodel_view, sh: *const mtr_rshader2, mat: *const mtr_rmaterial,
                                        textures: *const *mut mtr_texture, ntextures: usize, out: *mut *mut mtr_model) -> i32;
+    // round 2 (mtr_files.h): skeleton -> skin palette, state objects by name, mip chains, VECTOR / MATRIX keys, track bindings
+    pub fn mtr_rmodel_palette(m: *const mtr_rmodel_view, local_mats: *const f32, out_palette: *mut f32, cap_mats: usize) -> i32;
+    pub fn mtr_rmodel_joint_index(m: *const mtr_rmodel_view, no: u32) -> i32;
+    pub fn mtr_texture_create_from_file_mips(dev: *mut mtr_device, data: *const c_void, len: usize, max_levels: u32, out: *mut *mut mtr_texture) -> i32;
+    pub fn mtr_state_from_names(blend_name: *const c_char, depth_stencil_name: *const c_char, rasterizer_name: *const c_char,
+                                out: *mut super::mtr_prim_state) -> i32;
+    pub fn mtr_model_states_from_files(model: *const mtr_rmodel_view, sh: *const mtr_rshader2, mat: *const mtr_rmaterial,
+                                       states: *mut super::mtr_prim_state, nstates: usize) -> i32;
+    pub fn mtr_rscheduler_key_floats(s: *const mtr_rscheduler, track: u32, k: u32, out: *mut f32, n: *mut u32) -> i32;
+    pub fn mtr_rscheduler_eval_floats(s: *const mtr_rscheduler, track: u32, frame: u32, out: *mut f32, n: *mut u32) -> i32;
+    pub fn mtr_rscheduler_find_track(s: *const mtr_rscheduler, name: *const c_char) -> i32;
+    pub fn mtr_rscheduler_apply(s: *const mtr_rscheduler, frame: u32, bindings: *const mtr_sdl_binding, nbindings: usize,
+                                parts_disp: *mut u8, nparts: usize, model_mats: *mut f32, ninstances: usize) -> i32;
+}
+/// one binding of a track to what the draw path animates (mtr_files.h: MTR_SDL_*)
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct mtr_sdl_binding {
+    pub track: u32,
+    pub target: u32,
+    pub index: u32,
 }
