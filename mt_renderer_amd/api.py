@@ -17,7 +17,7 @@ import numpy as np
 from .scene import ModelData, TextureData
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmtr.so")
+LIB_PATH = os.environ.get("MTR_LIB_PATH") or os.path.join(_PKG, "libmtr.so")  # MTR_LIB_PATH: A/B runs of two builds on one box
 
 MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW = range(6)
 TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY, TILE_MIXED = 0, 1, 2, 3

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
             P.depth[pi] = cd;
         }
         if (P.mixed && threadIdx.x == 0) P.bin_flag[bin] = 0;
+        // the parked count of an empty bin is 0 too (mtr_frame_read_bin_counts: what bench.py balances bands by); without
+        // this store the word keeps whatever the allocation, or an earlier scene, left there
+        if (P.fb.direct && threadIdx.x == 0 && !ovf) P.fb.bin_count[bin] = 0ull;
         return;
     }
     for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;

@@ -208,3 +208,29 @@ def test_culling_is_conservative_on_hostile_inputs(gpu_device, seed):
             for cull in (True, False):
                 assert (res[cull][0][own] == full[0][own]).all() and (res[cull][1].view(np.uint32)[own] == full[1].view(np.uint32)[own]).all(), (seed, own_map, rank, cull)
             assert res[True][2]["tris_setup"] == res[False][2]["tris_setup"] and res[True][2]["bin_entries"] == res[False][2]["bin_entries"]
+
+
+def test_bin_counts_of_empty_bins_are_zero_whatever_the_buffer_held(gpu_device):
+    """mtr_frame_read_bin_counts is what bench.py balances bands by.  A frame after a larger model was freed and the target
+    grew gets its per-bin words from memory that held other data: every bin, empty ones included, must report its own
+    count (the empty-bin fast path of the visibility kernel used to leave the word alone)."""
+    from mt_renderer_amd import api
+    big = api.Model.new(gpu_device, scene.headline_model())
+    big.set_palette(scene.bone_palette())
+    M = scene.to_f32_colmajor(scene.headline_transform(640, 360))
+    for _ in range(6):
+        fr = api.Frame(gpu_device, 640, 360); big.render(fr, M); fr.end(); fr.close()
+    big.close()  # 14 MB of vertex / index data back to the allocator
+    w, h = 2560, 1440
+    small = api.Model.new(gpu_device, scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=12, cols=20))
+    mats, pals = scene.instance_lattice(4, 2)
+    batch = api.Batch(gpu_device, small, mats, pals, None)
+    vp = scene.to_f32_colmajor(scene.reference_view_proj(w, h))
+    try:
+        for k in range(4):  # every frame slot once
+            fr = api.Frame(gpu_device, w, h); fr.draw_batch(batch, vp); fr.end()
+            e, s = fr.bin_counts(); st = fr.stats(); fr.close()
+            assert int(e.astype(np.uint64).sum()) == st["bin_entries"], k
+            assert (e == 0).sum() > len(e) // 2  # most of the frame is empty
+    finally:
+        batch.close(); small.close()

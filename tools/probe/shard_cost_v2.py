@@ -51,9 +51,12 @@ def row_weights(make_unsharded, W, H):
     """entries per bin row of the unsharded frame + a constant per bin: what balanced bands equalise"""
     fr = make_unsharded(); fr.submit(); fr.wait()
     e, _ = fr.bin_counts()
+    fr_entries = fr.stats()["bin_entries"]
     fr.close()
     nbx, nby, _ = sharding.grid(W, H)
-    return e.reshape(nby, nbx).sum(axis=1).astype(np.float64) + 8.0 * nbx
+    rows = e.reshape(nby, nbx).sum(axis=1)
+    print(f"  calibration frame: {int(e.sum())} entries in the bin queues (frame statistics: {fr_entries}), rows with entries {int((rows > 0).sum())} of {nby}", flush=True)
+    return rows.astype(np.float64) + 8.0 * nbx
 
 
 def run(name, W, H, draw, nframes):
@@ -88,14 +91,14 @@ if what in ("headline", "all"):
     W, H = 1920, 1080
     md = scene.headline_model(); pal = scene.bone_palette(); M = scene.to_f32_colmajor(scene.headline_transform(W, H))
     model = api.Model.new(dev, md); model.set_palette(pal)
-    run("headline 1M tris 1080p", W, H, lambda fr: model.render(fr, M), 400)
+    run("headline 1M tris 1080p", W, H, lambda fr: model.render(fr, M), 4000)
     model.close()
 if what in ("c4", "all"):
     W, H = 3840, 2160
     vp = scene.to_f32_colmajor(scene.reference_view_proj(W, H))
     mats, pals = scene.instance_lattice(16, 8)
     m = api.Model.new(dev, scene.mesh50k()); batch = api.Batch(dev, m, mats, pals, None)
-    run("C4 128 inst 4K", W, H, lambda fr: fr.draw_batch(batch, vp), 200)
+    run("C4 128 inst 4K", W, H, lambda fr: fr.draw_batch(batch, vp), 1000)
     batch.close(); m.close()
 if what in ("c5", "all"):
     W, H = 3840, 2160
@@ -103,7 +106,7 @@ if what in ("c5", "all"):
     mats, pals = scene.instance_lattice(32, 32)
     texs = [scene.random_bc7_texture(1024, 1024, seed=200 + i, opaque_modes_only=True) for i in range(64)]
     m = api.Model.new(dev, scene.mesh50k(textured=True, textures=texs)); batch = api.Batch(dev, m, mats, pals, [i // 16 for i in range(1024)])
-    run("C5 1024 inst BC7 4K", W, H, lambda fr: fr.draw_batch(batch, vp), 40)
+    run("C5 1024 inst BC7 4K", W, H, lambda fr: fr.draw_batch(batch, vp), 200)
     batch.close(); m.close()
 dev.close()
 if out_path:
