@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) void k_tile(TileParams P) {
     const uint32_t lane = threadIdx.x;
     const uint32_t nbx = P.fb.nbx;
     uint32_t bin;
-    if (!block_to_bin(P.fb, bin)) return;
+    if (!block_to_bin(P.fb, bin, P.xcd_run)) return;
     if (P.mixed && !P.bin_flag[bin]) return;  // mixed frame: k_tile_vis has rendered this bin (only opaque triangles in it)
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
 
@@ -491,6 +491,7 @@ void mtr_launch_tile(const TileParams& p, bool textured, hipStream_t s) {
     const uint32_t mine = p.fb.own.own_count;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
+    if (p.xcd_run) grid = (grid / 8 + p.xcd_run - 1) / p.xcd_run * p.xcd_run * 8;  // whole runs
     if (textured) hipLaunchKernelGGL(mtr::k_tile<true>, dim3(grid), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(mtr::k_tile<false>, dim3(grid), dim3(64), 0, s, p);
 }

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t ovf = tile_prologue(P);
     uint32_t bin;
-    if (!block_to_bin(P.fb, bin)) return;  // uniform over the workgroup, before any barrier
+    if (!block_to_bin(P.fb, bin, P.xcd_run)) return;  // uniform over the workgroup, before any barrier
     const uint32_t nbx = P.fb.nbx;
     const int32_t binx0 = (int32_t)(bin % nbx) * MTR_BIN, biny0 = (int32_t)(bin / nbx) * MTR_BIN;
     const float cd = P.clear_depth;
@@ -375,6 +375,7 @@ void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
     const uint32_t mine = p.fb.own.own_count;
     if (mine == 0) return;
     uint32_t grid = (mine + 7) / 8 * 8;
+    if (p.xcd_run) grid = (grid / 8 + p.xcd_run - 1) / p.xcd_run * p.xcd_run * 8;  // whole runs
     int waves = 2;
     if (p.vis_waves) waves = (int)p.vis_waves;
     else if (mine <= 1536) waves = 8;   // 256 CUs: every bin is resident at once, the heaviest bin bounds the frame

@@ -160,9 +160,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // XCD-aware bin order: blocks b, b+8, ... share an XCD's L2: give each XCD a contiguous run of this rank's bins
 // (own_list is row-major for interleaved / band ownership and super-tile-major for super-tiles).
 // Returns false when this block has no bin.
-__device__ __forceinline__ bool block_to_bin(const FrameBuffers& fb, uint32_t& bin) {
+__device__ __forceinline__ bool block_to_bin(const FrameBuffers& fb, uint32_t& bin, uint32_t run = 0) {
     const uint32_t per = (gridDim.x + 7) / 8;
-    const uint32_t slot = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const uint32_t x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    // run == 0: XCD x takes one contiguous eighth of the bins; run > 0: runs of `run` consecutive bins are dealt to the
+    // XCDs in turn (the launch covers whole runs), so every XCD sees every region of the frame
+    const uint32_t slot = run ? ((i / run) * 8 + x) * run + (i % run) : x * per + i;
     if (slot >= fb.own.own_count) return false;
     bin = fb.own.own_list ? fb.own.own_list[slot] : slot;
     return bin < fb.nbx * fb.nby;
