@@ -130,13 +130,17 @@ def main():
     shard = gathered = final = None
     own = None  # (map, param, band rows) of the sharded frames
     if sharded:
-        # Ownership: bands of bin rows (MTR_OWN_BANDS), so that a rank only processes the geometry that can reach its
-        # band (the library culls the rest before any vertex work), balanced by one unsharded calibration frame: every
-        # rank renders it, reads the queue length of each bin and cuts the rows into `world` bands of equal weight
-        # (entries + a constant per bin).  The counts are exact integers, so every rank derives the same bands without
-        # talking to the others.  MTR_BENCH_OWNERSHIP=interleaved|bands|supertiles overrides.
+        # Ownership: equal bands of bin rows (MTR_OWN_BANDS), so that a rank only processes the geometry that can reach
+        # its band (the library culls the rest before any vertex work).  MTR_BENCH_OWNERSHIP=bands-balanced cuts the rows
+        # into `world` bands of equal WEIGHT instead, from one unsharded calibration frame (every rank renders it, reads
+        # the queue length of each bin; the counts are exact integers, so every rank derives the same bands without
+        # talking to the others).  On this 53 us frame balanced bands do not pay (worst rank, one GPU standing in for
+        # every rank, profiles/r02_c_shard_cost_v2.txt: 45.0 / 32.7 / 30.3 us per frame with equal bands at N = 2 / 4 / 8,
+        # 46.9 / 33.1 / 32.6 balanced) and they make the all-gather block -- the LARGEST share, padded -- 1.5x larger at
+        # N = 8 (13 of 68 rows instead of 8.5); on C4 / C5 they do (C5 at N = 8: 255 -> 219 us).
+        # MTR_BENCH_OWNERSHIP=interleaved|bands|bands-balanced|supertiles overrides.
         from mt_renderer_amd import sharding
-        kind = os.environ.get("MTR_BENCH_OWNERSHIP", "bands-balanced")
+        kind = os.environ.get("MTR_BENCH_OWNERSHIP", "bands")
         if kind == "interleaved":
             own = (api.OWN_INTERLEAVED, 0, None)
         elif kind == "supertiles":

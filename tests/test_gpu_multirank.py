@@ -26,7 +26,7 @@ def test_two_ranks_one_gpu_gathered_frame_matches_unsharded():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ownership", ["interleaved", "supertiles"])
+@pytest.mark.parametrize("ownership", ["interleaved", "supertiles", "bands-balanced"])
 def test_two_ranks_one_gpu_other_ownership_maps(ownership):
     env = dict(os.environ, MTR_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", MTR_BENCH_OWNERSHIP=ownership)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
