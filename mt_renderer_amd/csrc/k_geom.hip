@@ -415,11 +415,15 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     // hands out workgroups in order, and four that leave at once per one that works halve the rate at which work starts.
     // (Fetching the group's 16 chunk descriptors together with the mask, lane = chunk, to take one load off the chain in
     // front of the vertex work: 192 vs 189 us, no gain.)
-    const uint32_t nxq = P.work_nx * 4u, ii = blockIdx.x / nxq, xq = blockIdx.x - ii * nxq, x = xq >> 2, q = xq & 3u;
+    const uint32_t nxq = P.work_nx * 4u, ii = blockIdx.x / nxq, xq = blockIdx.x - ii * nxq, x = xq >> 2, q = xq & 3u;  // slots [0, grid / nxq)
     const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
     if (ii >= nlive) return;  // before touching anything else: a dead slot must cost no memory traffic
-    const uint32_t m16 = P.work_mask[(size_t)ii * P.work_nx + x];
+    // the mask through a SCALAR load (the aligned dword that holds it: a 16-bit load of a uniform address is still a
+    // vector-memory load, ~1 us under load, and the instance-list load waited behind it)
+    const size_t mi = (size_t)ii * P.work_nx + x;
+    const uint32_t mword = reinterpret_cast<const uint32_t*>(P.work_mask)[mi >> 1];
     const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
+    const uint32_t m16 = (mi & 1u) ? mword >> 16 : mword & 0xFFFFu;
     const uint32_t k = (uint32_t)__popc(m16);
     if (q * 4u >= k) return;
     stage_palette(P, inst, s_pal);
@@ -433,6 +437,41 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     float M[16];
     compose_matrix(P, inst, M);
     geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+}
+
+// The instance slots the full-rate launch of k_geom<MODE, true> does not cover (mtr_launch_geom): MTR_GEOM_REST_SPLIT
+// workgroups per slot.  Nearly always the slot is past the end of the instance list and they leave; otherwise each walks
+// every MTR_GEOM_REST_SPLIT-th mask of the instance itself, four survivors at a time (the palette is staged once per
+// workgroup).  Sixteen per slot: a single straggling instance costs ~13 sequential steps (~0.06 ms), hundreds of them fill the
+// chip as the full-rate launch would.  Its own kernel: the loop's register allocation must not touch the hot kernel's.
+#define MTR_GEOM_REST_SPLIT 16u
+template <int MODE>
+__global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
+    extern __shared__ __align__(16) float s_pal[];
+    __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
+    __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t split = min(P.work_nx, MTR_GEOM_REST_SPLIT);
+    const uint32_t ii = P.work_slot_base + blockIdx.x / split;
+    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    if (ii >= nlive) return;
+    const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
+    stage_palette(P, inst, s_pal);
+    float M[16];
+    compose_matrix(P, inst, M);
+    for (uint32_t x = blockIdx.x % split; x < P.work_nx; x += split) {
+        const uint32_t m16 = P.work_mask[(size_t)ii * P.work_nx + x];
+        const uint32_t k = (uint32_t)__popc(m16);
+        for (uint32_t nth = wave; nth < k; nth += 4) {
+            uint32_t mm = m16;
+            for (uint32_t t = 0; t < nth; t++) mm &= mm - 1u;
+            const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
+            const DChunk ch = P.chunks[c];
+            const DPrim pr = P.prims[ch.prim];
+            geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+        }
+    }
 }
 
 __device__ __forceinline__ void compose_vp_model(const float (&vp)[16], const float* model_mats, uint32_t inst, float (&M)[16]) {
@@ -483,8 +522,8 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
         for (int t = 0; t < 3; t++) { u.lo[t] = wave_min_f32(cb.lo[t]); u.hi[t] = wave_max_f32(cb.hi[t]); }
         FrameBuffers fb = {};
         fb.W = P.W; fb.H = P.H; fb.nbx = P.nbx; fb.nby = P.nby; fb.own = P.own;
-        keep = clipbox_may_touch_rank(u, fb) || P.own.cull >= 3u;  // 3, 4: timing ablations (MTR_CULL_DEBUG), keep everything
-        inside = (keep && clipbox_all_in_rank(u, fb)) || P.own.cull == 4u;
+        keep = clipbox_may_touch_rank(u, fb) || P.own.cull == 3u || P.own.cull == 4u;  // 3, 4: timing ablations (MTR_CULL_DEBUG), keep everything
+        inside = (keep && (clipbox_all_in_rank(u, fb) || P.own.cull == 5u)) || P.own.cull == 4u;  // 5: no chunk tests for kept instances
     }
     if (!keep) {
         if (lane == 0) atomicAdd(&P.counters[MTR_CTR(CTR_CULL, inst)], P.nchunks);  // statistics only
@@ -597,10 +636,26 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     size_t lds = (size_t)p.npal * 64;
     if (p.work_mask) {
         // sharded: four workgroups per group of 16 chunks and instance slot (what k_cull_chunks kept of them is on the device)
-        dim3 grid(p.work_nx * 4u * p.ninst);  // the host checked that this fits 31 bits
+        // The instance list's length is only known on the device, and a slot past its end costs ~0.2 ns per workgroup
+        // (204 of them per slot on mesh50k: 160 k idle workgroups were 32 us of the 188 us k_geom took on C5 as rank 3 of
+        // 8).  So the full-rate launch covers twice the rank's fair share of slots, and a second, small launch -- sixteen
+        // workgroups per remaining slot, which walk the instance's masks themselves -- covers the rest: almost always
+        // every one of them leaves at once; when a rank does keep more, they are exact and only a little slower.
+        uint32_t slots = p.ninst;
+        if (p.inst_count && p.fb.own.world > 1) slots = std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world + 64u);  // 64 more cost 3 us
+        if (const char* e = getenv("MTR_GEOM_SLOTS")) slots = std::min<uint32_t>(p.ninst, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tests force the second launch
+        dim3 grid(p.work_nx * 4u * slots);  // the host checked that this fits 31 bits
         if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
         else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);
+        if (slots < p.ninst) {
+            GeomParams r = p;
+            r.work_slot_base = slots;
+            dim3 rest((p.ninst - slots) * std::min<uint32_t>(p.work_nx, MTR_GEOM_REST_SPLIT));
+            if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom_rest<2>), rest, dim3(256), lds, s, r);
+            else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom_rest<1>), rest, dim3(256), lds, s, r);
+            else hipLaunchKernelGGL((mtr::k_geom_rest<0>), rest, dim3(256), lds, s, r);
+        }
         return;
     }
     uint32_t nblk = (p.nchunks + 3) / 4;

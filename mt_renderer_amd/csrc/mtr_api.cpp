@@ -1617,7 +1617,7 @@ static int32_t run_frame(mtr_frame* f) {
             const uint64_t nx = ((uint64_t)m->chunks.size() + 15) / 16;
             if (nx * 4 * dr.ninst > 0x7FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
             work_off[di] = (uint32_t)work_total;
-            work_total += nx * dr.ninst;
+            work_total += (nx * dr.ninst + 1) & ~1ull;  // even: k_geom reads a mask through the aligned dword that holds it
             if (!dr.d_model_mats) continue;  // a single model: chunk culling only
             if (sk ? (!m->inst_skinned_boundable || m->n_inst_skinned == 0) : (m->n_inst_unskinned == 0)) continue;
             inst_off[di] = (uint32_t)ninst_total;
@@ -1702,7 +1702,7 @@ static int32_t run_frame(mtr_frame* f) {
             cc.fb = fb;
             cc.comp = inst_cnt ? sl.comp + comp_off[di] : nullptr;
             cc.work_mask = sl.work_mask + work_off[di];
-            cc.keep_all = fb.own.cull >= 3u ? 1u : 0u;
+            cc.keep_all = (fb.own.cull == 3u || fb.own.cull == 4u) ? 1u : 0u;
             mtr_launch_cull_chunks(cc, sg);
             gp.work_mask = cc.work_mask; gp.work_nx = (gp.nchunks + 15u) / 16u;
             gp.inst_list = cc.inst_list; gp.inst_count = cc.inst_count;

@@ -286,8 +286,9 @@ struct GeomParams {
     // workgroup stores its mask, geometry workgroup (x, quarter q, ii) takes the q-th four set bits.  (Round 2 first
     // appended the survivors to 64 sub-lists: one returning atomic per cull workgroup, one more dependent load in front
     // of every geometry workgroup.)
-    const uint16_t* work_mask;
+    const uint16_t* work_mask;   // 4-byte aligned, an even number of masks allocated
     uint32_t work_nx;          // groups of 16 chunks per instance = ceil(nchunks / 16)
+    uint32_t work_slot_base;   // k_geom_rest: the first instance slot of its launch
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instance slot ii is instance ii
     const uint32_t* inst_count;  // length of inst_list (device), or nullptr: ninst
     const float* model_mats;  // ninst*16 or nullptr
