@@ -148,7 +148,8 @@ struct mtr_device {
     // costs the stand-alone kernel 2-3 us (locality) and gains 4-5 % of pipelined throughput on the headline scene
     // (0.0541 -> 0.0516 ms per frame, four runs each; runs of 16 / 60 bins: 0.0518 / 0.0514), neutral on C3-C5.
     // Unsharded frames only: a rank's band is a few rows (N = 4, 8: 32.6 -> 35.5, 30.3 -> 35.0 us per frame with runs).
-    // MTR_TILE_RUN overrides (0 = contiguous eighths).
+    // And only while the previous frame is still on the GPU (one event query per frame): a frame that has the GPU to
+    // itself keeps the contiguous order and its shorter kernel.  MTR_TILE_RUN overrides (0 = contiguous eighths).
     static constexpr uint32_t kXcdRunAuto = 0xFFFFFFFFu;
     uint32_t xcd_run = kXcdRunAuto;
     mtr_model* cube = nullptr;  // debug-overlay cube, created lazily
@@ -1732,7 +1733,16 @@ static int32_t run_frame(mtr_frame* f) {
     f->fb.next_zeroed = fb.own.own_count != 0;  // a rank without a bin launches no tile workgroup
     tp.host_status = d->status_dev + sidx;
     tp.vis_waves = d->vis_waves;
-    tp.xcd_run = d->xcd_run != mtr_device::kXcdRunAuto ? d->xcd_run : (fb.own.world <= 1 ? std::max(16u, nbx / 4u) : 0u);
+    {
+        // the previous frame still on the GPU: this one will share it, balance across the XCDs wins; otherwise the frame
+        // has the GPU to itself and the contiguous order's locality gives the shorter kernel (latency)
+        bool shared = false;
+        if (this_frame > 0) {
+            hipEvent_t prev = d->inflight[(this_frame - 1) % d->max_inflight];
+            shared = prev && hipEventQuery(prev) == hipErrorNotReady;
+        }
+        tp.xcd_run = d->xcd_run != mtr_device::kXcdRunAuto ? d->xcd_run : ((fb.own.world <= 1 && shared) ? std::max(16u, nbx / 4u) : 0u);
+    }
     if (fb.own.cull && fb.own.own_count) {  // this frame's tile kernel clears the slot's culling counters for the next one
         tp.zero_words = sl.inst_count; tp.zero_nwords = (uint32_t)ndraws * MTR_CULL_CTR_WORDS;
         sl.cull_counts_dirty = false;
