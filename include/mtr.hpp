@@ -43,7 +43,7 @@ class Device {
     }
     // waits for every frame in flight; reports (once) an overflow latched by a frame nobody waited for
     void synchronize() const { check(mtr_device_synchronize(h_)); }
-    void set_culling(bool on) const { check(mtr_device_set_culling(h_, on ? 1 : 0)); }  // sharded frames: per-rank geometry culling
+    void set_culling(int32_t mode) const { check(mtr_device_set_culling(h_, mode)); }  // MTR_GEOM_CULL_OFF / _SHARDED (default) / _ALL_FRAMES
     void set_texture_residency(uint32_t mode) const { check(mtr_device_set_texture_residency(h_, mode)); }  // MTR_TEXRES_*
     void exchange_drain() const { check(mtr_device_exchange_drain(h_)); }
     void exchange_stop() const { check(mtr_device_exchange_stop(h_)); }

@@ -23,6 +23,7 @@ MTR_OK, MTR_E_INVALID, MTR_E_UNSUPPORTED, MTR_E_NOMEM, MTR_E_HIP, MTR_E_OVERFLOW
 TILE_AUTO, TILE_ORDERED, TILE_VISIBILITY, TILE_MIXED = 0, 1, 2, 3
 OWN_INTERLEAVED, OWN_BANDS, OWN_SUPERTILES = 0, 1, 2
 TEXRES_DECODED, TEXRES_BLOCKS = 0, 1
+GEOM_CULL_OFF, GEOM_CULL_SHARDED, GEOM_CULL_ALL_FRAMES = 0, 1, 2
 STAGE_NAMES = ("geom", "scan", "fill", "tile")
 
 # every symbol include/mtr.h declares (tests check that the library exports each one)
@@ -219,9 +220,10 @@ class Device:
     def exchange_stop(self):
         self.check(lib.mtr_device_exchange_stop(self._h))
 
-    def set_culling(self, on: bool):
-        """sharded frames: skip geometry whose bounds cannot reach the rank's bins (default on)"""
-        self.check(lib.mtr_device_set_culling(self._h, 1 if on else 0))
+    def set_culling(self, mode):
+        """skip geometry whose bounds cannot reach the rank's bins: False / True (sharded frames, default) or
+        GEOM_CULL_ALL_FRAMES (unsharded frames too: what is off the target is skipped; include/mtr.h)"""
+        self.check(lib.mtr_device_set_culling(self._h, int(mode)))
 
     def set_texture_residency(self, mode: int):
         """what BC textures created from now on keep in HBM: TEXRES_DECODED (RGBA8, default) or TEXRES_BLOCKS (include/mtr.h)"""

@@ -338,6 +338,15 @@ __device__ __forceinline__ bool clipbox_all_in_rank(const ClipBox& u, const Fram
     const float my = 1.0f + 9.5367431640625e-07f * fmaxf(fabsf(fy_lo), fabsf(fy_hi));
     fy_lo -= my; fy_hi += my;
     if (!(fy_lo == fy_lo && fy_hi == fy_hi)) return false;
+    if (fb.own.world <= 1) {  // an unsharded frame (MTR_GEOM_CULL_ALL_FRAMES): "all in" = wholly on the target, so that the
+                              // chunks of an instance that hangs over its edge are still tested one by one
+        const float xlo = u.lo[0], xhi = u.hi[0];
+        const float sx_lo = xlo >= 0.0f ? xlo / whi : xlo / wlo, sx_hi = xhi >= 0.0f ? xhi / wlo : xhi / whi;
+        const float fW = (float)fb.W, hw = 0.5f * fW;
+        const float fx_lo = sx_lo * hw + hw, fx_hi = sx_hi * hw + hw;
+        const float mx = 1.0f + 9.5367431640625e-07f * fmaxf(fabsf(fx_lo), fabsf(fx_hi));
+        return fx_lo - mx >= 0.0f && fx_hi + mx <= fW && fy_lo >= 0.0f && fy_hi <= fH;  // false for NaN
+    }
     const uint32_t by0 = (uint32_t)fminf(fmaxf(fy_lo, 0.0f), fH) >> MTR_BIN_SHIFT;
     const uint32_t by1 = min((uint32_t)fminf(fmaxf(fy_hi, 0.0f), fH) >> MTR_BIN_SHIFT, fb.nby - 1u);
     return rect_owned_all(fb.own, min(by0, fb.nby - 1u), by1);

@@ -141,6 +141,7 @@ struct mtr_device {
     std::vector<std::pair<uint64_t, uint32_t>> fb_allocated;  // (w << 32 | h) -> colour / depth sets ever allocated
     std::vector<std::unique_ptr<OwnTable>> own_tables;  // grow-only cache (submit_mu)
     bool cull_enabled = true;   // sharded frames cull chunks / instances against the rank's bins
+    bool cull_unsharded = false;  // MTR_GEOM_CULL_ALL_FRAMES: unsharded frames cull against the target too (frustum culling)
     uint32_t vis_waves = 0;     // MTR_VIS_WAVES: waves per bin of the visibility kernel, 0 = by the number of bins
     // Tile-kernel bin order across the 8 XCDs.  One contiguous eighth of the bins per XCD keeps the records of
     // neighbouring bins in one L2 and gives the shortest stand-alone kernel (48.9 us), but the XCDs that own the empty top
@@ -1296,9 +1297,12 @@ int32_t mtr_device_set_texture_residency(mtr_device* d, uint32_t mode) {
     return MTR_OK;
 }
 
-int32_t mtr_device_set_culling(mtr_device* d, int32_t enable) {
+int32_t mtr_device_set_culling(mtr_device* d, int32_t mode) {
     if (!d) return MTR_E_INVALID;
-    d->cull_enabled = enable != 0;
+    if (mode < MTR_GEOM_CULL_OFF || mode > MTR_GEOM_CULL_ALL_FRAMES) return fail(d, MTR_E_INVALID, "unknown culling mode");
+    std::lock_guard<std::mutex> g(d->submit_mu);
+    d->cull_enabled = mode != MTR_GEOM_CULL_OFF;
+    d->cull_unsharded = mode == MTR_GEOM_CULL_ALL_FRAMES;
     return MTR_OK;
 }
 
@@ -1578,6 +1582,9 @@ static int32_t run_frame(mtr_frame* f) {
         // is next to nothing to cull (and the work list would only cost): culling is for bands and super-tiles
         fb.own.cull = (d->cull_enabled && t.map != MTR_OWN_INTERLEAVED) ? 1u : 0u;
         if (const char* e = getenv("MTR_CULL_DEBUG")) fb.own.cull = (uint32_t)strtol(e, nullptr, 10);  // timing ablations only
+    }
+    else if (d->cull_unsharded && d->cull_enabled) {
+        fb.own.cull = 1u;  // world 1: "a bin of this rank" = a bin of the target, so what is culled is what is off the target
     }
     fb.direct = f->ran_direct ? 1u : 0u; fb.qcap = d->qcap; fb.scap = d->scap;
     // every material opaque (debug / overlay colours have a == 1; opaque textures sample a == 1): the frame is a

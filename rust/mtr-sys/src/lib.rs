@@ -137,7 +137,7 @@ extern "C" {
     pub fn mtr_crc32(bytes: *const u8, len: usize, init: u32) -> u32;
     // round 2
     pub fn mtr_device_synchronize(dev: *mut mtr_device) -> i32;
-    pub fn mtr_device_set_culling(dev: *mut mtr_device, enable: i32) -> i32;
+    pub fn mtr_device_set_culling(dev: *mut mtr_device, mode: i32) -> i32; // MTR_GEOM_CULL_OFF / _SHARDED / _ALL_FRAMES = 0 / 1 / 2
     pub fn mtr_device_set_texture_residency(dev: *mut mtr_device, mode: u32) -> i32;
     pub fn mtr_texture_create_mips(dev: *mut mtr_device, width: u32, height: u32, format: u32, levels: u32, data: *const c_void,
                                    len: usize, out: *mut *mut mtr_texture) -> i32;

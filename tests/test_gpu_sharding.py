@@ -257,3 +257,33 @@ def test_instances_beyond_the_full_rate_launch_take_the_slow_exact_path(gpu_devi
         assert (part[0][own] == full[0][own]).all() and (part[1].view(np.uint32)[own] == full[1].view(np.uint32)[own]).all(), rank
         for key in ("tris_setup", "bin_entries", "chunks_culled"):
             assert part[2][key] == ref[rank][2][key], (rank, key)
+
+
+def test_unsharded_frames_can_cull_what_is_off_the_target(gpu_device):
+    """MTR_GEOM_CULL_ALL_FRAMES: the culling of sharded frames applied to an unsharded one = frustum culling.  A lattice of
+    instances seen by a camera that has most of it out of view: same pixels and counts as without, most chunks skipped;
+    a single model hanging over the edge of the target too."""
+    from mt_renderer_amd import api
+    w, h = 640, 360
+    small = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=24, cols=40)
+    mats, pals = scene.instance_lattice(8, 6)
+    base = scene.reference_view_proj(w, h)
+    views = [scene.to_f32_colmajor(base @ scene.mat_translate(dx, dy, dz)) for dx, dy, dz in ((0.0, 0.0, 0.0), (2.2, 0.9, 0.0), (-1.5, 0.0, 1.2), (0.0, 0.0, 2.1))]
+    big = scene.mesh50k()
+    Mbig = scene.to_f32_colmajor(base @ scene.mat_translate(-5.0 + 1.4, 0.6, 1.0 - 2.0))  # half of it past the right / top edge
+    try:
+        for vp in views:
+            draws = [dict(md=small, vp=vp, model_mats=mats, palettes=pals), dict(md=big, M=Mbig, palette=scene.bone_palette())]
+            gpu_device.set_culling(api.GEOM_CULL_SHARDED)
+            ref = render_gpu(gpu_device, w, h, draws)
+            gpu_device.set_culling(api.GEOM_CULL_ALL_FRAMES)
+            got = render_gpu(gpu_device, w, h, draws)  # every queue builder x both tile kernels inside
+            assert (got[0] == ref[0]).all() and (got[1].view(np.uint32) == ref[1].view(np.uint32)).all()
+            for key in ("tris_setup", "bin_entries", "chunks"):
+                assert got[2][key] == ref[2][key], key
+            assert ref[2]["chunks_culled"] == 0 and got[2]["chunks_culled"] > 0
+        assert got[2]["chunks_culled"] > got[2]["chunks"] // 2  # the last view: behind the camera / out of sight, mostly
+    finally:
+        gpu_device.set_culling(api.GEOM_CULL_SHARDED)
+    with pytest.raises(api.MtrError):
+        gpu_device.set_culling(7)
