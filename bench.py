@@ -8,16 +8,26 @@
 A "step" is one frame: clear (fused) -> geometry -> bin -> tile raster/shade -> framebuffer complete in
 HBM (N > 1: after the RCCL all-gather of the colour shards).  All inputs (vertex/index buffers, bone
 palette, transforms) are resident in HBM before the timed region.  One process per GPU; N > 1 shards
-the 16x16-pixel bins over the ranks (bin % N == rank) and exchanges colour with one all-gather.
+the 16x16-pixel bins over the ranks (bands of bin rows; a rank culls the geometry that cannot reach its
+band) and exchanges colour with one all-gather.
+
+The timed region is EXACTLY `--steps` frames between two (barrier + synchronize) pairs, as the driver's
+contract says; it is repeated R = ceil(0.2 s / (steps x estimated frame time)) times and `ms_per_step` is
+the MEDIAN repetition (a 20-step region lasts 1 ms: one sample of it is mostly noise).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HBM-bound accounting, hipEvent
 timing on the library's own stream) and `cpu_baseline` (the CPU oracle -- kind "port": the
-reference has no CPU path at all -- on a bounded sample of the same workload, N = 1 only).
+reference has no CPU path at all -- on a bounded sample of the same workload, N = 1 only).  N > 1
+(or --configs) adds `configs`: BASELINE.json's multi-GPU configs C4 (128 instances, 3840x2160) and C5
+(1024 instances, 64 BC7 textures, 3840x2160) sharded over the N ranks, next to the same scene rendered
+unsharded in the same run, and efficiency = t1 / (N x tN).
 """
 import argparse
 import json
+import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -63,6 +73,33 @@ def algorithmic_bytes(md, width, height, npalettes, nbones=64):
     return geom + tile, geom, tile
 
 
+class Watchdog:
+    """N > 1: a rank that stops making progress (a peer died, a collective that never completes) must end the job with
+    a message that says where, not sit in the driver's clock until it is killed.  One timer per phase; when it fires the
+    process reports its phase and how far it got, and exits -- a fresh exit (os._exit), never a re-exec."""
+
+    def __init__(self, rank, enabled):
+        self.rank, self.enabled, self.timer, self.progress = rank, enabled, None, 0
+
+    def arm(self, label, seconds):
+        self.disarm()
+        if not self.enabled:
+            return
+        def fire():
+            print(f"[rank {self.rank}] WATCHDOG: no completion of '{label}' after {seconds:.0f} s (frames issued by this rank in the "
+                  f"phase: {self.progress}); a peer rank failed or a collective cannot complete -- exiting", file=sys.stderr, flush=True)
+            os._exit(6)
+        self.progress = 0
+        self.timer = threading.Timer(seconds, fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +109,11 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--verify", action="store_true", help="N > 1: compare the gathered frame with an unsharded render")
+    ap.add_argument("--verify", action="store_true", help="N > 1: compare every gathered frame (headline, C4, C5) with an unsharded render")
+    ap.add_argument("--configs", choices=["auto", "on", "off"], default="auto",
+                    help="time BASELINE configs C4 / C5 too (auto: when N > 1, where they are defined)")
+    ap.add_argument("--config-steps", type=int, default=100, help="frames per timed region of a C4 / C5 leg")
+    ap.add_argument("--config-instances", type=int, default=0, help="rehearsals: C5 with this many instances instead of 1024 (C4: a quarter)")
     args = ap.parse_args()
 
     # N > 1: more hardware queues than ROCm's default 4, so that the exchange (public stream + RCCL's stream) does not
@@ -106,8 +147,18 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
+    watchdog = Watchdog(rank, sharded)
+    wd_seconds = float(os.environ.get("MTR_BENCH_WATCHDOG_S", "240"))
 
-    from mt_renderer_amd import api, scene
+    from mt_renderer_amd import api, scene, sharding
+
+    def all_ok(ok):
+        """the same answer on every rank: did the step succeed on ALL of them (MIN all-reduce)"""
+        if not sharded:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     W, H = args.width, args.height
     md = scene.headline_model()
@@ -117,223 +168,297 @@ def main():
 
     stream = torch.cuda.Stream()
     dev = api.Device(dev_index, stream=stream.cuda_stream)
-    model = api.Model.new(dev, md)
-    model.set_palette(palette)
 
-    # N > 1: each rank renders bins (bin % N == rank), packs them bin-major (csrc/k_shard.hip), one RCCL
-    # all-gather over xGMI exchanges W*H*4/N bytes per rank, one unpack kernel rebuilds the linear frame
-    # The exchange of a frame is pack -> all-gather -> unpack on the device's public stream (which the library makes wait
-    # for each frame), while later frames render on the library's internal streams.  That only overlaps if the runtime
-    # gives those streams separate hardware queues: with ROCm's default of 4 the exchange shared a queue with the
-    # render streams and a frame took 0.089 ms instead of 0.057 (tools/probe/nccl_one_rank.py), hence
-    # GPU_MAX_HW_QUEUES=8 above.  Rotating several exchange streams was measured too and is worse (more queues to share).
-    shard = gathered = final = None
-    own = None  # (map, param, band rows) of the sharded frames
-    if sharded:
-        # Ownership: equal bands of bin rows (MTR_OWN_BANDS), so that a rank only processes the geometry that can reach
-        # its band (the library culls the rest before any vertex work).  MTR_BENCH_OWNERSHIP=bands-balanced cuts the rows
-        # into `world` bands of equal WEIGHT instead, from one unsharded calibration frame (every rank renders it, reads
-        # the queue length of each bin; the counts are exact integers, so every rank derives the same bands without
-        # talking to the others).  On this 53 us frame balanced bands do not pay (worst rank, one GPU standing in for
-        # every rank, profiles/r02_c_shard_cost_v2.txt: 45.0 / 32.7 / 30.3 us per frame with equal bands at N = 2 / 4 / 8,
-        # 46.9 / 33.1 / 32.6 balanced) and they make the all-gather block -- the LARGEST share, padded -- 1.5x larger at
-        # N = 8 (13 of 68 rows instead of 8.5); on C4 / C5 they do (C5 at N = 8: 255 -> 219 us).
-        # MTR_BENCH_OWNERSHIP=interleaved|bands|bands-balanced|supertiles overrides.
-        from mt_renderer_amd import sharding
-        kind = os.environ.get("MTR_BENCH_OWNERSHIP", "bands")
+    class Workload:
+        """one scene resident in HBM: a single model (headline) or an instanced batch (C4 / C5)"""
+
+        def __init__(self, name, w, h, mdata, *, view, pal=None, model_mats=None, palettes=None, tex_override=None):
+            self.name, self.w, self.h, self.md = name, w, h, mdata
+            self.model = api.Model.new(dev, mdata)
+            self.batch = None
+            self.view = view
+            if model_mats is not None:
+                self.batch = api.Batch(dev, self.model, model_mats, palettes, tex_override)
+                self.ntris = mdata.input_triangles() * int(model_mats.shape[0])
+            else:
+                self.model.set_palette(pal)
+                self.ntris = mdata.input_triangles()
+
+        def draw(self, fr):
+            if self.batch is not None:
+                fr.draw_batch(self.batch, self.view)
+            else:
+                self.model.render(fr, self.view)
+
+        def frame_loop(self, shard, exchange):
+            return api.FrameLoop(dev, self.w, self.h, model=None if self.batch is not None else self.model, batch=self.batch,
+                                 view_proj=self.view, shard=shard, exchange=exchange)
+
+        def close(self):
+            if self.batch is not None:
+                self.batch.close()
+            self.model.close()
+
+    headline = Workload("headline", W, H, md, view=M, pal=palette)
+
+    def choose_ownership(work, kind):
+        """(map, param, band rows) of the sharded frames of a workload.  Bands of bin rows, so that a rank only processes
+        the geometry that can reach its band (the library culls the rest before any vertex work).  "bands-balanced" cuts
+        the rows into `world` bands of equal WEIGHT from one unsharded calibration frame (every rank renders it and reads
+        the queue length of each bin; the counts are exact integers, so every rank derives the same bands without talking
+        to the others).  On the 53 us headline frame balanced bands do not pay (profiles/r02_c_shard_cost_v2.txt) and make
+        the all-gather block -- the LARGEST share, padded -- 1.5x larger at N = 8; on C4 / C5 they do."""
         if kind == "interleaved":
-            own = (api.OWN_INTERLEAVED, 0, None)
-        elif kind == "supertiles":
-            own = (api.OWN_SUPERTILES, 3, None)
-        elif kind == "bands":
-            own = (api.OWN_BANDS, 0, sharding.equal_bands(H, world))
-        else:
-            fr = api.Frame(dev, W, H); model.render(fr, M); fr.end()
-            entries, _ = fr.bin_counts()
-            fr.close()
-            nbx, nby, _ = sharding.grid(W, H)
-            own = (api.OWN_BANDS, 0, sharding.balanced_bands(entries.reshape(nby, nbx).sum(axis=1).astype(np.float64) + 8.0 * nbx, world))
+            return (api.OWN_INTERLEAVED, 0, None)
+        if kind == "supertiles":
+            return (api.OWN_SUPERTILES, 3, None)
+        if kind == "bands":
+            return (api.OWN_BANDS, 0, sharding.equal_bands(work.h, world))
+        fr = api.Frame(dev, work.w, work.h)
+        work.draw(fr)
+        fr.end()
+        entries, _ = fr.bin_counts()
+        fr.close()
+        nbx, nby, _ = sharding.grid(work.w, work.h)
+        return (api.OWN_BANDS, 0, sharding.balanced_bands(entries.reshape(nby, nbx).sum(axis=1).astype(np.float64) + 8.0 * nbx, world))
+
+    # ---- the communicator: ncclAllGather called straight from ctypes (~3 us of host time per frame instead of ~20-30 us
+    # for dist.all_gather_into_tensor, which matters once a rank's share of the frame is below 30 us of GPU time).
+    # Every rank must take the same path: agree on it with a MIN all-reduce after each step that can fail.
     rc = None  # direct RCCL communicator (mt_renderer_amd/rccl.py), or None: torch.distributed's collective
-    xthread = False  # the exchange runs on the library's exchange thread
-    xstream = None
-    lane2 = None  # second exchange lane: (communicator, send, gathered, final, stream)
-    if sharded:
-        nbytes = api.shard_bytes_map(W, H, world, *own)
-        shard = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
-        final = torch.empty(W * H * 4, dtype=torch.uint8, device="cuda")
-        if backend == "nccl" and os.environ.get("MTR_BENCH_TORCH_COLLECTIVE") != "1":
-            # ncclAllGather called straight from ctypes: ~3 us of host time per frame instead of ~20-30 us for
-            # dist.all_gather_into_tensor, which matters once a rank's share of the frame is below 30 us of GPU time.
-            # Every rank must take the same path: agree on it with a MIN all-reduce after each step that can fail.
-            def all_ok(ok):
-                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item())
-            import threading
-            from mt_renderer_amd import rccl
+    want_xthread = False
+    rccl = None
+    if sharded and backend == "nccl" and os.environ.get("MTR_BENCH_TORCH_COLLECTIVE") != "1":
+        from mt_renderer_amd import rccl
 
-            def make_comm(what):
-                """a communicator of this job's ranks, or None on EVERY rank if any step failed on any of them"""
+        def make_comm(what):
+            """a communicator of this job's ranks, or None on EVERY rank if any step failed on any of them"""
+            try:
+                c = rccl.Rccl()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] direct RCCL unavailable ({e}); {what}", file=sys.stderr)
+                c = None
+            if not all_ok(c is not None):
+                return None
+            uid = None
+            if rank == 0:
                 try:
-                    c = rccl.Rccl()
+                    uid = c.unique_id()
                 except Exception as e:  # noqa: BLE001
-                    print(f"[rank {rank}] direct RCCL unavailable ({e}); {what}", file=sys.stderr)
-                    c = None
-                if not all_ok(c is not None):
-                    return None
-                uid = None
-                if rank == 0:
-                    try:
-                        uid = c.unique_id()
-                    except Exception as e:  # noqa: BLE001
-                        print(f"[rank 0] ncclGetUniqueId failed ({e}); {what}", file=sys.stderr)
-                box = [uid]
-                dist.broadcast_object_list(box, src=0)
-                ok = False
-                if box[0] is not None:
-                    # ncclCommInitRank is a blocking collective: if it cannot complete, end the run instead of hanging
-                    guard = threading.Timer(180.0, lambda: (print(f"[rank {rank}] ncclCommInitRank did not return in 180 s",
-                                                                  file=sys.stderr, flush=True), os._exit(5)))
-                    guard.daemon = True
-                    guard.start()
-                    try:
-                        c.init(box[0], world, rank)
-                        ok = True
-                    except Exception as e:  # noqa: BLE001
-                        print(f"[rank {rank}] ncclCommInitRank failed ({e}); {what}", file=sys.stderr)
-                    guard.cancel()
-                return c if all_ok(ok) else None
+                    print(f"[rank 0] ncclGetUniqueId failed ({e}); {what}", file=sys.stderr)
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            ok = False
+            if box[0] is not None:
+                # ncclCommInitRank is a blocking collective: if it cannot complete, end the run instead of hanging
+                guard = threading.Timer(180.0, lambda: (print(f"[rank {rank}] ncclCommInitRank did not return in 180 s",
+                                                              file=sys.stderr, flush=True), os._exit(5)))
+                guard.daemon = True
+                guard.start()
+                try:
+                    c.init(box[0], world, rank)
+                    ok = True
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] ncclCommInitRank failed ({e}); {what}", file=sys.stderr)
+                guard.cancel()
+            return c if all_ok(ok) else None
 
-            rc = make_comm("using torch.distributed")
-            # With the direct communicator the whole exchange of a frame (pack -> ncclAllGather -> unpack -> destroy) moves
-            # to the library's exchange thread (include/mtr.h: mtr_device_exchange_start): a rank's loop then costs the
-            # host ~28-31 us per frame instead of ~43-51 (tools/probe/exchange_thread.py), which is what bounds N > 1 on this
-            # frame.  MTR_BENCH_EXCHANGE_THREAD=0 keeps everything on one thread.
-            if rc is not None and os.environ.get("MTR_BENCH_EXCHANGE_THREAD") != "0":
-                xstream = torch.cuda.Stream()
+        rc = make_comm("using torch.distributed")
+        # With the direct communicator the whole exchange of a frame (pack -> ncclAllGather -> unpack -> destroy) moves
+        # to the library's exchange thread (include/mtr.h: mtr_device_exchange_start): a rank's loop then costs the
+        # host ~28-31 us per frame instead of ~43-51 (tools/probe/exchange_thread.py), which is what bounds N > 1 on the
+        # headline frame.  MTR_BENCH_EXCHANGE_THREAD=0 keeps everything on one thread.
+        want_xthread = rc is not None and os.environ.get("MTR_BENCH_EXCHANGE_THREAD") != "0"
+    rc2 = None  # communicator of a second exchange lane (MTR_BENCH_EXCHANGE_LANES=2; an experiment for real multi-GPU nodes:
+    # on the one GPU where it can be measured the extra stream costs more than it hides, 0.091 vs 0.057 ms per frame)
+    if want_xthread and int(os.environ.get("MTR_BENCH_EXCHANGE_LANES", "1")) > 1:
+        rc2 = make_comm("one exchange lane")
+
+    class Exchange:
+        """buffers + (optionally) the library's exchange thread for the sharded frames of ONE workload under ONE map"""
+
+        def __init__(self, work, own):
+            self.work, self.own = work, own
+            self.nbytes = api.shard_bytes_map(work.w, work.h, world, *own)
+            self.shard = torch.empty(self.nbytes, dtype=torch.uint8, device="cuda")
+            self.gathered = torch.empty(self.nbytes * world, dtype=torch.uint8, device="cuda")
+            self.final = torch.zeros(work.w * work.h * 4, dtype=torch.uint8, device="cuda")
+            self.xthread, self.lane2, self.xstream = False, None, None
+            if want_xthread:
+                self.xstream = torch.cuda.Stream()
                 started = False
                 try:
-                    dev.exchange_start(rc.allgather_addr, rc.comm_handle, rccl.ncclUint8, shard.data_ptr(), shard.numel(),
-                                       gathered.data_ptr(), final.data_ptr(), world, xstream.cuda_stream)
+                    dev.exchange_start(rc.allgather_addr, rc.comm_handle, rccl.ncclUint8, self.shard.data_ptr(), self.shard.numel(),
+                                       self.gathered.data_ptr(), self.final.data_ptr(), world, self.xstream.cuda_stream)
                     started = True
                 except Exception as e:  # noqa: BLE001
                     print(f"[rank {rank}] exchange thread unavailable ({e}); exchanging on the render thread", file=sys.stderr)
                 if all_ok(started):
-                    xthread = True
+                    self.xthread = True
                 elif started:
                     dev.exchange_stop()
-            # A lane is an in-order stream: it completes one (pack + all-gather + unpack) latency per frame.  A second lane
-            # with its own communicator takes every other frame, so two collectives are in flight -- but it is one more
-            # busy stream, and on the one GPU where it can be measured (world of one rank, the GPU rendering whole frames)
-            # the extra stream costs more than it hides: 0.091 ms per frame against 0.057 with one lane, for any
-            # GPU_MAX_HW_QUEUES from 8 to 24.  Off by default; MTR_BENCH_EXCHANGE_LANES=2 turns it on for an experiment on
-            # a real multi-GPU node, where the all-gather's latency may be what bounds the exchange stream.
-            want_lanes = int(os.environ.get("MTR_BENCH_EXCHANGE_LANES", "1"))
-            if xthread and want_lanes > 1:
-                rc2 = make_comm("one exchange lane")
-                if rc2 is not None:
+                if self.xthread and rc2 is not None:
                     added = False
                     try:
-                        lane2 = (rc2, torch.empty_like(shard), torch.empty_like(gathered), torch.empty_like(final), torch.cuda.Stream())
-                        dev.exchange_add_lane(rc2.comm_handle, lane2[1].data_ptr(), lane2[2].data_ptr(), lane2[3].data_ptr(),
-                                              lane2[4].cuda_stream)
+                        self.lane2 = (rc2, torch.empty_like(self.shard), torch.empty_like(self.gathered), torch.zeros_like(self.final), torch.cuda.Stream())
+                        dev.exchange_add_lane(rc2.comm_handle, self.lane2[1].data_ptr(), self.lane2[2].data_ptr(), self.lane2[3].data_ptr(),
+                                              self.lane2[4].cuda_stream)
                         added = True
                     except Exception as e:  # noqa: BLE001
                         print(f"[rank {rank}] second exchange lane unavailable ({e})", file=sys.stderr)
                     if not all_ok(added):
                         # the lane count must be the same on every rank: without agreement, go back to the render thread
                         dev.exchange_stop()
-                        xthread = False
-                        lane2 = None
+                        self.xthread, self.lane2 = False, None
+            torch.cuda.synchronize()  # the buffers exist (torch's stream made them) before another stream touches them
 
-    # the timed loop body with every argument marshalled once (api.FrameLoop): begin -> set_shard -> draw -> submit
-    # [-> hand-over to the exchange thread] -> destroy, the same C calls as the classes make
-    loop = api.FrameLoop(dev, W, H, model=model, view_proj=M, shard=(rank, world) + own if sharded else None, exchange=xthread)
-
-    def one_frame(check=False):
-        if not check and (xthread or not sharded):
-            loop.run(1)
-            return
-        fr = api.Frame(dev, W, H)
-        if sharded:
-            fr.set_shard(rank, world, *own)
-        model.render(fr, M)
-        if check or not xthread:
-            fr.submit()
-        if check:
-            fr.wait()  # grows the bin queues if needed and validates device flags
-        if xthread:
-            fr.submit_exchange()  # the exchange thread packs, gathers, unpacks and destroys the frame
-            return
-        if sharded:
-            fr.pack_color_shard(shard.data_ptr(), shard.numel())
+        def inline(self, fr):
+            """pack -> all-gather -> unpack on the device's public stream (no exchange thread)"""
+            fr.pack_color_shard(self.shard.data_ptr(), self.shard.numel())
             if rc is not None:
-                rc.all_gather_u8(shard.data_ptr(), gathered.data_ptr(), shard.numel(), stream.cuda_stream)
-            with torch.cuda.stream(stream):
-                if rc is not None:
-                    pass
-                elif backend == "nccl":
-                    dist.all_gather_into_tensor(gathered, shard)
-                else:  # rehearsal: host-staged gather
-                    stream.synchronize()
-                    host = torch.empty(gathered.numel(), dtype=torch.uint8)
-                    dist.all_gather_into_tensor(host, shard.cpu())
-                    gathered.copy_(host)
-            fr.unpack_color_shards(gathered.data_ptr(), final.data_ptr())
-        fr.close()
+                rc.all_gather_u8(self.shard.data_ptr(), self.gathered.data_ptr(), self.shard.numel(), stream.cuda_stream)
+            else:
+                with torch.cuda.stream(stream):
+                    if backend == "nccl":
+                        dist.all_gather_into_tensor(self.gathered, self.shard)
+                    else:  # rehearsal: host-staged gather
+                        stream.synchronize()
+                        host = torch.empty(self.gathered.numel(), dtype=torch.uint8)
+                        dist.all_gather_into_tensor(host, self.shard.cpu())
+                        self.gathered.copy_(host)
+            fr.unpack_color_shards(self.gathered.data_ptr(), self.final.data_ptr())
 
-    def sync():
-        if xthread:
-            dev.exchange_drain()  # every handed-over frame has been issued
-        torch.cuda.synchronize()
-        dev.synchronize()  # raises if a frame nobody waited for overflowed its bin queues (it would be missing triangles)
+        def close(self):
+            if self.xthread:
+                dev.exchange_stop()
+                self.xthread = False
+
+    def sync(ex, what):
+        """every frame issued so far is complete on every rank, and no rank is in error: a rank whose exchange or whose
+        frames failed still took part in every collective (the library sends a clear-colour shard), reports here, and ALL
+        ranks leave together -- nobody is left waiting for a peer that has gone"""
+        err = None
+        try:
+            if ex is not None and ex.xthread:
+                dev.exchange_drain()  # every handed-over frame has been issued; raises the exchange thread's first error
+            torch.cuda.synchronize()
+            dev.synchronize()  # raises if a frame nobody waited for overflowed its bin queues (it would be missing triangles)
+        except api.MtrError as e:
+            err = e
         if sharded:
+            if not all_ok(err is None):
+                print(f"[rank {rank}] {what}: {'FAILED: ' + str(err) if err else 'ok here, another rank failed'}; every rank exits", file=sys.stderr, flush=True)
+                watchdog.disarm()
+                sys.exit(4)
             dist.barrier()
             torch.cuda.synchronize()
+        elif err is not None:
+            raise err
 
-    one_frame(check=True)
-    # Device warm-up, untimed and independent of --warmup: the GPU's power management raises its clocks some 40 ms
-    # after sustained load begins (one ~35 ms stall, then 52 us per frame instead of 58: tools/probe/hiccup.py), so a
-    # short run would time the transition instead of the steady state.  0.3 s of the same frames first.
-    if sharded:
-        for _ in range(3000 if backend == "nccl" else 20):  # a fixed count: every rank must make the same number of collective calls
-            one_frame()
-    else:
-        t_ramp = time.perf_counter() + 0.3
-        while time.perf_counter() < t_ramp:
-            for _ in range(50):
-                one_frame()
-    for _ in range(args.warmup):
-        one_frame()
-    sync()
-    t0 = time.perf_counter()
-    if xthread or not sharded:
-        loop.run(args.steps)
-    else:
-        for _ in range(args.steps):
-            one_frame()
-    sync()
-    dt = time.perf_counter() - t0
-    if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if args.verify and sharded:
-        fr = api.Frame(dev, W, H)
-        model.render(fr, M)
+    def run_frames(work, ex, loop, n, shard_args):
+        """n frames, submitted back to back, nothing waited for"""
+        if ex is None or ex.xthread:
+            loop.run(n)
+            watchdog.progress += n
+            return
+        for _ in range(n):
+            fr = api.Frame(dev, work.w, work.h)
+            fr.set_shard(*shard_args)
+            work.draw(fr)
+            fr.submit()
+            ex.inline(fr)
+            fr.close()
+            watchdog.progress += 1
+
+    def checked_frame(work, ex, shard_args):
+        """one frame with a host-side wait: grows the bin queues if needed and validates the device flags"""
+        fr = api.Frame(dev, work.w, work.h)
+        if shard_args:
+            fr.set_shard(*shard_args)
+        work.draw(fr)
+        fr.submit()
+        fr.wait()
+        if ex is None:
+            fr.close()
+        elif ex.xthread:
+            fr.submit_exchange()
+        else:
+            ex.inline(fr)
+            fr.close()
+
+    def time_leg(work, ex, shard_args, steps, warmup, ramp_frames, ramp_seconds, min_reps=1, budget_s=0.2):
+        """(ms per step: median repetition, every repetition's ms per step, repetitions).  A timed region = exactly `steps`
+        frames between two sync()s; max over the ranks per region."""
+        loop = work.frame_loop(shard_args, ex is not None and ex.xthread)
+        watchdog.arm(f"{work.name}: first frame + clock ramp", wd_seconds)
+        checked_frame(work, ex, shard_args)
+        # Device warm-up, untimed and independent of --warmup: the GPU's power management raises its clocks some 40 ms
+        # after sustained load begins (one ~35 ms stall, then 52 us per frame instead of 58: tools/probe/hiccup.py), so a
+        # short run would time the transition instead of the steady state.
+        sync(ex, f"{work.name} first frame")
+        t_r0 = time.perf_counter()
+        # sharded: a fixed count, every rank must make the same number of collective calls
+        run_frames(work, ex, loop, ramp_frames, shard_args)
+        n_ramp = ramp_frames
+        if not sharded:
+            t_ramp = time.perf_counter() + ramp_seconds
+            while time.perf_counter() < t_ramp:
+                run_frames(work, ex, loop, 50, shard_args)
+                n_ramp += 50
+        sync(ex, f"{work.name} clock ramp")
+        est = (time.perf_counter() - t_r0) / max(1, n_ramp)  # seconds per frame, roughly
+        reps = max(min_reps, min(400, math.ceil(budget_s / max(1e-6, steps * est))))
+        if sharded:  # the same count on every rank
+            t = torch.tensor([reps], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            reps = int(t.item())
+        watchdog.arm(f"{work.name}: warm-up + {reps} timed regions of {steps} frames", wd_seconds)
+        run_frames(work, ex, loop, warmup, shard_args)
+        sync(ex, f"{work.name} warm-up")
+        dts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run_frames(work, ex, loop, steps, shard_args)
+            sync(ex, f"{work.name} timed region")
+            dts.append(time.perf_counter() - t0)
+        watchdog.disarm()
+        if sharded:
+            t = torch.tensor(dts, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = [float(v) for v in t.cpu()]
+        per_step = sorted(d * 1e3 / steps for d in dts)
+        return float(np.median(per_step)), per_step, reps
+
+    def verify_leg(work, ex):
+        """the gathered frame(s) this rank holds == the same scene rendered unsharded on this rank, bit for bit"""
+        fr = api.Frame(dev, work.w, work.h)
+        work.draw(fr)
         fr.end()
         ref = fr.color()
         fr.close()
-        sync()
-        got = final.cpu().numpy().reshape(H, W, 4)
+        torch.cuda.synchronize()
+        got = ex.final.cpu().numpy().reshape(work.h, work.w, 4)
         ok = bool((got == ref).all())
-        if lane2 is not None:  # odd frames went through the second lane into its own destination
-            ok = ok and bool((lane2[3].cpu().numpy().reshape(H, W, 4) == ref).all())
-        print(f"[rank {rank}] verify gathered frame == unsharded frame: {ok}", file=sys.stderr, flush=True)
-        if not ok:
+        if ex.lane2 is not None:  # odd frames went through the second lane into its own destination
+            ok = ok and bool((ex.lane2[3].cpu().numpy().reshape(work.h, work.w, 4) == ref).all())
+        print(f"[rank {rank}] verify {work.name}: gathered frame == unsharded frame: {ok}", file=sys.stderr, flush=True)
+        return ok
+
+    # ---- headline leg (the metric) ----
+    own = choose_ownership(headline, os.environ.get("MTR_BENCH_OWNERSHIP", "bands")) if sharded else None
+    shard_args = (rank, world) + own if sharded else None
+    ex = Exchange(headline, own) if sharded else None
+    xthread = bool(ex and ex.xthread)
+    lane2 = ex.lane2 if ex else None
+    ms_per_step, per_step, reps = time_leg(headline, ex, shard_args, args.steps, args.warmup,
+                                           (3000 if backend == "nccl" else 20) if sharded else 50, 0.3)
+    verified = {}
+    if args.verify and sharded:
+        verified["headline"] = verify_leg(headline, ex)
+        if not all_ok(verified["headline"]):
             sys.exit(3)
-    ms_per_step = dt * 1e3 / args.steps
+    if ex is not None:
+        ex.close()
     mtris = ntris / (ms_per_step * 1e-3) / 1e6
 
     # ---- roofline: per-stage hipEvent timing on the library's streams, separate from the timed region ----
@@ -350,13 +475,12 @@ def main():
     depth = 6
     stats = None
     inflight = []
-    shard_args = (rank, world) + own if sharded else None
 
     def new_frame():
         fr = api.Frame(dev, W, H)
         if sharded:
             fr.set_shard(*shard_args)
-        model.render(fr, M)
+        headline.draw(fr)
         return fr
 
     def retire(fr):
@@ -409,23 +533,85 @@ def main():
     dom = max(("geom", "tile"), key=lambda k: stage_ms[k])
     achieved = alg[dom] / (stage_ms[dom] * 1e-3) / 1e9
     # achieved / frac: the dominant kernel's OWN algorithmic bytes over its average launch duration in the pipelined
-    # pattern of the timed region (what rocprofv3 --stats of this command reports); `kernels` has both kernels, each
-    # also against its stand-alone duration; `frame_*`: the whole frame's algorithmic bytes over the measured ms_per_step
+    # pattern of the timed region (what rocprofv3 --stats of this command reports); frac_standalone: the same bytes over
+    # the kernel's duration with nothing else on the GPU; `kernels` has both kernels; `frame_*`: the whole frame's
+    # algorithmic bytes over the measured ms_per_step
     roofline = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": kernels[dom]["traffic"],
-                "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage_ms[dom], 5),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_standalone": kernels[dom]["frac_standalone"],
+                "traffic": kernels[dom]["traffic"],
+                "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage_ms[dom], 5), "kernel_ms_standalone": round(stage_ms_serial[dom], 5),
+                "note": "kernel_ms > ms_per_step is stream concurrency, not an inconsistency: three frames' kernels are co-resident "
+                        "on three streams, so a launch lasts longer than a step; frac uses that overlapped duration (what rocprofv3 "
+                        "--stats of this command reports), frac_standalone the kernel alone on the GPU",
                 "kernels": kernels,
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                 "stage_ms_serial": {k: round(v, 5) for k, v in stage_ms_serial.items()},
                 "frame_algorithmic_bytes": alg_frame,
                 "frame_gbps": round(alg_frame / (ms_per_step * 1e-3) / 1e9, 3),
                 "frame_frac": round(alg_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "residency_note": "the bench re-renders one frame whose ~80 MB of traffic fit the 256 MB Infinity Cache: `traffic` counts "
+                                  "fabric requests, not DRAM; FETCH_SIZE x2 (gfx950 correction for wide streaming reads) overstates 32-byte record gathers",
                 "traffic_source": ("profiles/pmc_traffic.json (kernel sources %s)" % kernel_source_hash()) if traffic_by_kernel else None}
     if direct:  # single-pass binning: k_scan / k_fill are not launched at all
         roofline["stage_note"] = "single-pass binning: no k_scan / k_fill launch (reported as 0)" + \
                                  ("; sharded frames: the geom stage includes the culling kernels" if sharded else "")
     latency = {"ms_per_frame_latency": round(med(lat_gpu), 5), "frames": len(lat_gpu), "definition": "SURVEY 8(d): one frame at a time, first kernel start to framebuffer complete in HBM (hipEvents on the frame's stream), median",
                "ms_per_frame_latency_host_clock": round(med(lat_host), 5), "mtris_per_s_at_latency": round(ntris / (med(lat_gpu) * 1e-3) / 1e6, 2)}
+
+    # ---- BASELINE configs C4 / C5: multi-GPU by definition ("sharded across 2/4/8 GPUs", "8 GPUs") ----
+    configs = None
+    if args.configs == "on" or (args.configs == "auto" and sharded):
+        configs = {}
+        n5 = args.config_instances or 1024
+        n4 = max(2, n5 // 8)
+
+        def lat(n):  # 1024 -> 32 x 32, 128 -> 16 x 8; powers of two in between for rehearsals
+            nx = 1 << (n.bit_length() // 2)
+            return nx, max(1, n // nx)
+        cw, chh = 3840, 2160
+        vp4k = scene.to_f32_colmajor(scene.reference_view_proj(cw, chh))
+        for cname in ("C4", "C5"):
+            nx, ny = lat(n4 if cname == "C4" else n5)
+            mats, pals = scene.instance_lattice(nx, ny)
+            ninst = nx * ny
+            if cname == "C4":
+                cmd = scene.mesh50k()
+                work = Workload("C4", cw, chh, cmd, view=vp4k, model_mats=mats, palettes=pals)
+                desc = f"{ninst} instanced mesh50k ({ninst * 50000} triangles), 64 bones each, debug-id shader, {cw}x{chh}"
+            else:
+                ntex = max(1, ninst // 16)
+                texs = [scene.random_bc7_texture(1024, 1024, seed=200 + i, opaque_modes_only=True) for i in range(ntex)]
+                cmd = scene.mesh50k(textured=True, textures=texs)
+                work = Workload("C5", cw, chh, cmd, view=vp4k, model_mats=mats, palettes=pals, tex_override=[i // 16 for i in range(ninst)])
+                desc = f"{ninst} instanced mesh50k ({ninst * 50000} triangles), {ntex} BC7 1024x1024 albedo textures (opaque set), textured shader, {cw}x{chh}"
+            steps_c = args.config_steps
+            # the same scene unsharded, on every rank at once (each on its own GPU): t1 (max over ranks, as every leg)
+            ramp_c = (200 if backend == "nccl" else 4) if sharded else 20
+            t1_ms, t1_all, reps1 = time_leg(work, None, None, steps_c, 20 if backend == "nccl" or not sharded else 2, ramp_c, 0.1, min_reps=3, budget_s=0.3)
+            entry = {"workload": desc, "triangles_per_frame": work.ntris, "steps": steps_c,
+                     "unsharded": {"ms_per_frame": round(t1_ms, 5), "mtris_per_s": round(work.ntris / (t1_ms * 1e-3) / 1e6, 1), "repetitions": reps1,
+                                   "where": "same run, same build: every rank renders it at the same time on its own GPU, the slowest counts"}}
+            if sharded:
+                own_c = choose_ownership(work, os.environ.get("MTR_BENCH_CONFIG_OWNERSHIP", "bands-balanced"))
+                sh_c = (rank, world) + own_c
+                ex_c = Exchange(work, own_c)
+                tn_ms, tn_all, repsn = time_leg(work, ex_c, sh_c, steps_c, 20 if backend == "nccl" else 2, ramp_c, 0.0, min_reps=3, budget_s=0.3)
+                if args.verify:
+                    verified[cname] = verify_leg(work, ex_c)
+                    if not all_ok(verified[cname]):
+                        sys.exit(3)
+                ex_c.close()
+                entry["sharded"] = {"ms_per_frame": round(tn_ms, 5), "mtris_per_s": round(work.ntris / (tn_ms * 1e-3) / 1e6, 1), "n_gpus": world,
+                                    "repetitions": repsn, "ms_per_frame_min_max": [round(tn_all[0], 5), round(tn_all[-1], 5)],
+                                    "bands": list(map(int, own_c[2])) if own_c[2] is not None else None,
+                                    "ownership": os.environ.get("MTR_BENCH_CONFIG_OWNERSHIP", "bands-balanced"),
+                                    "definition": "frames submitted back to back; a frame is complete when the gathered 4K colour buffer is on every rank (after the all-gather and the unpack); max over ranks"}
+                entry["efficiency"] = round(t1_ms / (world * tn_ms), 4)
+                entry["efficiency_definition"] = "t1 / (N x tN): unsharded ms/frame over N times the sharded ms/frame, same run"
+            configs[cname] = entry
+            work.close()
+        if backend != "nccl" and sharded:
+            configs["note"] = "rehearsal backend (gloo through host memory, every rank on one GPU): plumbing only, the times mean nothing"
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -452,6 +638,8 @@ def main():
         out = {
             "metric": "Mtris/sec, 1M-tri 64-bone skinned scene @1920x1080", "value": round(mtris, 2), "unit": "Mtris/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "repetitions": reps, "ms_per_step_min_max": [round(per_step[0], 5), round(per_step[-1], 5)],
+            "ms_per_step_is": "the median of `repetitions` timed regions of exactly `steps` frames each (every region bracketed by barrier + synchronize)",
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "headline: 20 x mesh50k primitives = 1,000,000 strip triangles, 506,520 vertices x 24 B, "
                                    "64-bone palette, debug-id shader, %dx%d" % (W, H),
@@ -463,15 +651,19 @@ def main():
             "latency": latency,
             "frame_stats": stats, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if configs is not None:
+            out["configs"] = configs
+        if verified:
+            out["verified"] = verified
         print(json.dumps(out))
-    model.close()
+    headline.close()
     dev.close()
     if sharded:
         if rc is not None:
             torch.cuda.synchronize()
             rc.close()
-            if lane2 is not None:
-                lane2[0].close()
+            if rc2 is not None:
+                rc2.close()
         dist.destroy_process_group()
 
 

@@ -287,7 +287,8 @@ int32_t mtr_device_exchange_stop(mtr_device *dev);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
 /* tuning / test hook: per-bin queue sizes of the frame just rendered (valid until the next frame is submitted on
- * this device): entries[b] = (triangle, bin) pairs of 16x16 bin b, segments[b] = ordered runs; nbins each */
+ * this device): entries[b] = (triangle, bin) pairs of 16x16 bin b, segments[b] = ordered runs; nbins each.  A sharded
+ * frame reports its own bins; the bins of the other ranks read 0. */
 int32_t mtr_frame_read_bin_counts(mtr_frame *frame, uint32_t *entries, uint32_t *segments, size_t nbins);
 void mtr_frame_destroy(mtr_frame *frame);
 

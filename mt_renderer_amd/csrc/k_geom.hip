@@ -13,7 +13,6 @@
 #include "geom_common.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace mtr {
 
@@ -643,8 +642,8 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
         // every one of them leaves at once; when a rank does keep more, they are exact and only a little slower.
         uint32_t slots = p.ninst;
         if (p.inst_count && p.fb.own.world > 1) slots = std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world + 64u);  // 64 more cost 3 us
-        if (const char* e = getenv("MTR_GEOM_SLOTS")) slots = std::min<uint32_t>(p.ninst, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tests force the second launch
-        dim3 grid(p.work_nx * 4u * slots);  // the host checked that this fits 31 bits
+        if (p.slots_override) slots = std::min<uint32_t>(p.ninst, p.slots_override);  // MTR_GEOM_SLOTS at device creation: tests force the second launch
+        dim3 grid(p.work_nx * 4u * slots);  // the host checked work_nx * 4 * ninst against the launch limit (2^32 threads)
         if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
         else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);

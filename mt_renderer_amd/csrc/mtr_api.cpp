@@ -87,6 +87,7 @@ struct OwnTable {
     std::vector<uint32_t> offs;   // world + 1: rank r's bins are lists[offs[r] .. offs[r+1])
     uint32_t stride_bins = 0;     // the largest share = bins per rank in an all-gather buffer
     uint32_t nsx = 0, st_shift = 0;
+    std::vector<uint32_t> lists;       // host copy of d_lists (mtr_frame_read_bin_counts masks the bins a rank does not own)
     uint32_t* d_lists = nullptr;       // nbins bin ids, rank after rank, each in tile-kernel order
     uint32_t* d_src_of_bin = nullptr;  // nbins: rank * stride_bins + k
     uint32_t refs = 0;                 // live frames that use it (submit_mu)
@@ -143,6 +144,11 @@ struct mtr_device {
     bool cull_enabled = true;   // sharded frames cull chunks / instances against the rank's bins
     bool cull_unsharded = false;  // MTR_GEOM_CULL_ALL_FRAMES: unsharded frames cull against the target too (frustum culling)
     uint32_t vis_waves = 0;     // MTR_VIS_WAVES: waves per bin of the visibility kernel, 0 = by the number of bins
+    // timing-ablation hooks, read ONCE at device creation (never in the submit path): MTR_CULL_DEBUG in {0, 1, 3, 4, 5}
+    // replaces the culling mode of maps that cull (k_geom.hip: k_cull_instances), MTR_GEOM_SLOTS bounds the instance
+    // slots the full-rate sharded geometry launch covers (tests force k_geom_rest with it); 0xFFFFFFFF / 0: not set
+    uint32_t cull_debug = 0xFFFFFFFFu;
+    uint32_t geom_slots = 0;
     // Tile-kernel bin order across the 8 XCDs.  One contiguous eighth of the bins per XCD keeps the records of
     // neighbouring bins in one L2 and gives the shortest stand-alone kernel (48.9 us), but the XCDs that own the empty top
     // and bottom of a frame run dry while the middle ones work; dealing runs of a quarter bin row to the XCDs in turn
@@ -194,12 +200,29 @@ struct mtr_texture {
     bool opaque;  // every decoded texel (of every level) has alpha == 255: sampling it yields a == 1 exactly
 };
 
+// The chunk table of a model under one parts_disp: immutable once built.  A draw holds the table that was current when
+// it was recorded (Model::render reads parts_disp while it records, src/model.rs:318-320), so a frame that is re-run
+// after a queue overflow -- possibly by the exchange thread, possibly after the host has changed parts_disp for a later
+// frame -- reproduces exactly what was submitted, and nobody rewrites a table a kernel or another thread is reading.
+struct ChunkTable {
+    int hip_dev = 0;
+    std::vector<DChunk> chunks;
+    DChunk* d_chunks = nullptr;
+    uint64_t ntris_visible = 0;
+    ~ChunkTable() {
+        if (!d_chunks) return;
+        (void)hipSetDevice(hip_dev);
+        (void)hipDeviceSynchronize();  // frames that drew with it may still be in flight; tables die rarely (parts_disp changed)
+        (void)hipFree(d_chunks);
+    }
+};
+
 struct mtr_model {
     mtr_device* dev;
     uint8_t* d_vbuf = nullptr;
     uint16_t* d_ibuf = nullptr;
     DPrim* d_prims = nullptr;
-    DChunk* d_chunks = nullptr;
+    std::shared_ptr<const ChunkTable> table;  // for the current parts_disp; rebuilt by the next draw when chunks_dirty (submit_mu)
     float* d_palette = nullptr;   // the current palette: one buffer of pal_ring
     uint32_t npal = 0;
     // mtr_model_set_palette does not wait for frames in flight: every call uploads into the next buffer of a ring
@@ -207,7 +230,9 @@ struct mtr_model {
     // model is drawn and its stream waits on the event.  A ring buffer comes round again only after max_inflight + 1
     // palette changes; if the last frame that read it can still be in flight (many changes, few frames) the call waits
     // for exactly that frame first.
-    // pinned: frames that drew the model with this buffer and have not been submitted yet (their kernels will read it)
+    // pinned: frames that drew the model with this buffer and may still (re-)run: recorded and not yet submitted, or
+    // submitted and their overflow flags not yet examined (a frame whose bin queues overflowed is run again); the pin is
+    // dropped when the flags turn out clean, or when the frame is destroyed
     struct PalBuf { float* d = nullptr; uint32_t cap = 0; hipEvent_t ready = nullptr; uint64_t last_frame = 0; bool used = false; uint32_t pinned = 0; };
     std::vector<PalBuf> pal_ring;
     size_t pal_next = 0;
@@ -222,8 +247,6 @@ struct mtr_model {
     std::vector<uint32_t> debug_rgba8;
     std::vector<mtr_prim_state> states;  // material state per primitive, empty: the reference's pipeline state
     std::vector<float> joint_cubes;      // one instance matrix per joint: scale 0.005, translation = offset * 0.01 (src/model.rs:309-315)
-    std::vector<DChunk> chunks;
-    uint64_t ntris_visible = 0;
     bool chunks_dirty = true;
     size_t vertex_len = 0;
     // culling bounds (multi-GPU v2), computed once at creation over every chunk of every primitive, whatever parts_disp
@@ -257,6 +280,7 @@ struct BatchDeleter {
 
 struct Draw {
     mtr_model* model;
+    std::shared_ptr<const ChunkTable> table;  // the model's chunk table when the draw was recorded
     const float* d_model_mats;  // nullptr: M = view_proj
     const float* d_palettes;
     hipEvent_t pal_ready;  // upload of d_palettes / d_model_mats on the copy stream (model palette ring, or the batch)
@@ -515,6 +539,7 @@ int32_t get_own_table(mtr_device* d, uint32_t w, uint32_t h, uint32_t world, uin
     if (rc) return rc;
     HIPCHK(d, hipMemcpy(t->d_lists, lists.data(), lists.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(d, hipMemcpy(t->d_src_of_bin, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    t->lists = std::move(lists);
     *out = t.get();
     d->own_tables.push_back(std::move(t));
     return MTR_OK;
@@ -670,9 +695,9 @@ void build_bounds(mtr_model* m, const uint8_t* vbuf, std::vector<BoneBox>& boxes
     m->inst_skinned_boundable = weights_ok;
 }
 
-void rebuild_chunks(mtr_model* m) {
-    m->chunks.clear();
-    m->ntris_visible = 0;
+void rebuild_chunks(const mtr_model* m, ChunkTable* t) {
+    t->chunks.clear();
+    t->ntris_visible = 0;
     for (size_t p = 0; p < m->prims.size(); p++) {
         const DPrim& pr = m->prims[p];
         if (pr.parts_no >= m->parts_disp.size() || !m->parts_disp[pr.parts_no]) continue;  // src/model.rs:318-320
@@ -695,11 +720,27 @@ void rebuild_chunks(mtr_model* m) {
             c.ntris = nt;
             const size_t sc = m->prim_chunk_base[p] + start / MTR_CHUNK_NEW;
             c.b_first = m->cb_first[sc]; c.b_count = m->cb_count[sc]; c.b_flags = m->cb_flags[sc] | (pr.skinnable ? 2u : 0u); c.pad = 0;
-            m->ntris_visible += nt;
-            m->chunks.push_back(c);
+            t->ntris_visible += nt;
+            t->chunks.push_back(c);
         }
     }
-    m->chunks_dirty = false;
+}
+
+// The model's chunk table for its current parts_disp, built and uploaded on first use.  submit_mu held.
+int32_t current_table(mtr_model* m, std::shared_ptr<const ChunkTable>* out) {
+    mtr_device* d = m->dev;
+    if (m->chunks_dirty || !m->table) {
+        auto t = std::make_shared<ChunkTable>();
+        t->hip_dev = d->hip_dev;
+        rebuild_chunks(m, t.get());
+        int32_t rc = dev_alloc(d, &t->d_chunks, t->chunks.size());
+        if (rc) return rc;
+        if (!t->chunks.empty()) HIPCHK(d, hipMemcpy(t->d_chunks, t->chunks.data(), t->chunks.size() * sizeof(DChunk), hipMemcpyHostToDevice));
+        m->table = std::move(t);
+        m->chunks_dirty = false;
+    }
+    *out = m->table;
+    return MTR_OK;
 }
 
 }  // namespace
@@ -744,6 +785,14 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
     if (const char* e = getenv("MTR_TILE_RUN")) {
         const long v = strtol(e, nullptr, 10);
         if (v >= 0 && v <= 65536) d->xcd_run = (uint32_t)v;
+    }
+    if (const char* e = getenv("MTR_CULL_DEBUG")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v == 0 || v == 1 || v == 3 || v == 4 || v == 5) d->cull_debug = (uint32_t)v;
+    }
+    if (const char* e = getenv("MTR_GEOM_SLOTS")) {
+        const long v = strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 0xFFFF) d->geom_slots = (uint32_t)v;
     }
     if (const char* e = getenv("MTR_MAX_INFLIGHT")) {
         const long v = strtol(e, nullptr, 10);
@@ -813,6 +862,7 @@ int32_t mtr_device_set_tile_mode(mtr_device* d, int32_t mode) {
 int32_t mtr_device_set_binning(mtr_device* d, int32_t single_pass, uint32_t queue_capacity) {
     if (!d) return MTR_E_INVALID;
     if (queue_capacity && (queue_capacity < 64 || queue_capacity > 65536)) return fail(d, MTR_E_INVALID, "queue capacity out of range");
+    std::lock_guard<std::mutex> g(d->submit_mu);  // the exchange thread grows the bound when it re-runs an overflowed frame
     d->direct_enabled = single_pass != 0;
     if (queue_capacity) { d->qcap = queue_capacity; d->scap = std::max<uint32_t>(16, queue_capacity / 8); }
     return MTR_OK;
@@ -1044,7 +1094,7 @@ void mtr_model_destroy(mtr_model* m) {
         if (pb.d) (void)hipFree(pb.d);
         if (pb.ready) (void)hipEventDestroy(pb.ready);
     }
-    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_chunks, m->d_boxes, m->d_inst_boxes};
+    void* ptrs[] = {m->d_vbuf, m->d_ibuf, m->d_prims, m->d_boxes, m->d_inst_boxes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete m;
@@ -1075,6 +1125,9 @@ int32_t mtr_model_set_prim_states(mtr_model* m, const mtr_prim_state* states, si
 
 int32_t mtr_model_set_parts_disp(mtr_model* m, const uint8_t* parts_disp, size_t n) {
     if (!m || (!parts_disp && n)) return MTR_E_INVALID;
+    // the exchange thread may be re-running a frame that drew this model: the table a recorded draw holds is immutable,
+    // and what the next draw will see changes under the lock
+    std::lock_guard<std::mutex> submit_lock(m->dev->submit_mu);
     m->parts_disp.assign(parts_disp, parts_disp + n);
     m->chunks_dirty = true;
     return MTR_OK;
@@ -1092,12 +1145,17 @@ int32_t mtr_model_set_palette(mtr_model* m, const float* mats, size_t n) {
     m->pal_ready = nullptr;
     m->pal_slot = -1;
     if (n) {
-        if (m->pal_ring.size() != (size_t)d->max_inflight + 1)  // first use (the bound is fixed at device creation)
+        if (m->pal_ring.size() < (size_t)d->max_inflight + 1)  // first use (the bound is fixed at device creation)
             m->pal_ring.resize((size_t)d->max_inflight + 1);
         size_t slot = m->pal_next++ % m->pal_ring.size();
         for (size_t tries = 0; m->pal_ring[slot].pinned && tries < m->pal_ring.size(); tries++) slot = m->pal_next++ % m->pal_ring.size();
-        if (m->pal_ring[slot].pinned)
-            return fail(d, MTR_E_INVALID, "every palette buffer of the model is held by a frame that was drawn and not yet submitted");
+        if (m->pal_ring[slot].pinned) {
+            // every buffer is held by a live frame that may still (re-)run: the host keeps more un-waited frames alive than
+            // the ring has buffers.  The ring grows by one (indices held by recorded draws stay valid).
+            if (m->pal_ring.size() >= 4096) return fail(d, MTR_E_NOMEM, "more than 4096 live frames hold a palette of this model");
+            m->pal_ring.emplace_back();
+            slot = m->pal_ring.size() - 1;
+        }
         mtr_model::PalBuf& pb = m->pal_ring[slot];
         // the last frame that read this buffer: finished for sure once max_inflight later frames have been submitted
         if (pb.used && d->frames_submitted < pb.last_frame + 1 + d->max_inflight && d->inflight[pb.last_frame % d->max_inflight])
@@ -1238,6 +1296,8 @@ int32_t mtr_frame_begin(mtr_device* d, uint32_t w, uint32_t h, const float clear
     return MTR_OK;
 }
 
+static void release_palette_pins(mtr_frame* f);
+
 void mtr_frame_destroy(mtr_frame* f) {
     if (!f) return;
     mtr_device* d = f->dev;
@@ -1249,11 +1309,10 @@ void mtr_frame_destroy(mtr_frame* f) {
         std::lock_guard<std::mutex> g(d->submit_mu);
         const_cast<OwnTable*>(f->own)->refs--;
     }
-    for (Draw& dr : f->draws)  // drawn, never submitted
-        if (dr.pal_pinned && dr.pal_slot >= 0 && (size_t)dr.pal_slot < dr.model->pal_ring.size()) {
-            std::lock_guard<std::mutex> g(d->submit_mu);
-            dr.model->pal_ring[(size_t)dr.pal_slot].pinned--;
-        }
+    {
+        std::lock_guard<std::mutex> g(d->submit_mu);
+        release_palette_pins(f);  // drawn and never submitted, or submitted and never waited for
+    }
     if (f->submitted && !f->flags_checked && f->status_idx >= 0) {
         // nobody looked at this frame's overflow flags: they are examined when its status word is polled or recycled,
         // and a frame that dropped triangles is then reported by the next call that can return an error
@@ -1306,21 +1365,27 @@ int32_t mtr_device_set_culling(mtr_device* d, int32_t mode) {
     return MTR_OK;
 }
 
-static int32_t check_model_for_draw(mtr_frame* f, mtr_model* m) {
+// validates the draw and snapshots the model's chunk table (its visible primitives) as of now
+static int32_t check_model_for_draw(mtr_frame* f, mtr_model* m, std::shared_ptr<const ChunkTable>* table) {
     mtr_device* d = f->dev;
     if (!m || m->dev != d) return fail(d, MTR_E_INVALID, "model belongs to another device");
     if (f->submitted) return fail(d, MTR_E_INVALID, "frame already submitted");
+    int32_t rc = set_device(d);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> submit_lock(d->submit_mu);
     for (size_t p = 0; p < m->prims.size(); p++)
         if (m->prims[p].parts_no >= m->parts_disp.size())  // self.parts_disp[parts_no] would panic, src/model.rs:318
             return fail(d, MTR_E_INVALID, "primitive " + std::to_string(p) + ": parts_no outside parts_disp");
-    return MTR_OK;
+    return current_table(m, table);
 }
 
 int32_t mtr_frame_draw_model(mtr_frame* f, mtr_model* m, const float view_proj[16]) {
     if (!f || !view_proj) return MTR_E_INVALID;
-    int32_t rc = check_model_for_draw(f, m);
+    std::shared_ptr<const ChunkTable> table;
+    int32_t rc = check_model_for_draw(f, m, &table);
     if (rc) return rc;
     Draw dr{};
+    dr.table = std::move(table);
     dr.model = m; dr.d_model_mats = nullptr; dr.d_palettes = m->d_palette; dr.npal = m->npal; dr.pal_ready = m->pal_ready; dr.pal_slot = m->pal_slot;
     dr.pal_stride = 0; dr.ninst = 1; dr.shader_override = -1; dr.blend = true;
     memcpy(dr.vp, view_proj, sizeof dr.vp);
@@ -1336,9 +1401,11 @@ int32_t mtr_frame_draw_model(mtr_frame* f, mtr_model* m, const float view_proj[1
 int32_t mtr_frame_draw_batch(mtr_frame* f, mtr_batch* b, const float view_proj[16]) {
     if (!f || !b || !view_proj) return MTR_E_INVALID;
     if (b->dev != f->dev) return fail(f->dev, MTR_E_INVALID, "batch belongs to another device");
-    int32_t rc = check_model_for_draw(f, b->model);
+    std::shared_ptr<const ChunkTable> table;
+    int32_t rc = check_model_for_draw(f, b->model, &table);
     if (rc) return rc;
     Draw dr{};
+    dr.table = std::move(table);
     dr.model = b->model; dr.d_model_mats = b->d_model_mats; dr.batch = b; dr.pal_ready = b->ready; dr.pal_slot = -1;
     dr.d_palettes = b->npal ? b->d_palettes : nullptr;
     dr.npal = b->npal; dr.pal_stride = b->npal * 16; dr.ninst = b->n;
@@ -1414,6 +1481,15 @@ int32_t mtr_frame_draw_overlay_cubes(mtr_frame* f, const float camera[16], const
     return MTR_OK;
 }
 
+// the frame can no longer (re-)run: its draws let go of the palette ring buffers they hold.  submit_mu held.
+static void release_palette_pins(mtr_frame* f) {
+    for (Draw& dr : f->draws)
+        if (dr.pal_pinned && dr.pal_slot >= 0 && (size_t)dr.pal_slot < dr.model->pal_ring.size()) {
+            dr.model->pal_ring[(size_t)dr.pal_slot].pinned--;
+            dr.pal_pinned = false;
+        }
+}
+
 // Enqueues every kernel of the frame.  The caller holds d->submit_mu.
 static int32_t run_frame(mtr_frame* f) {
     mtr_device* d = f->dev;
@@ -1424,16 +1500,9 @@ static int32_t run_frame(mtr_frame* f) {
     uint64_t total_chunks = 0, nmats = 0, tris_in = 0;
     for (auto& dr : f->draws) {
         mtr_model* m = dr.model;
-        if (m->chunks_dirty) {
-            rebuild_chunks(m);
-            if (m->d_chunks) { if ((rc = drain_all(d))) return rc; (void)hipFree(m->d_chunks); m->d_chunks = nullptr; }
-            if ((rc = dev_alloc(d, &m->d_chunks, m->chunks.size()))) return rc;
-            HIPCHK(d, hipMemcpyAsync(m->d_chunks, m->chunks.data(), m->chunks.size() * sizeof(DChunk), hipMemcpyHostToDevice, d->stream));
-            HIPCHK(d, hipStreamSynchronize(d->stream));
-        }
-        total_chunks += (uint64_t)m->chunks.size() * dr.ninst;
+        total_chunks += (uint64_t)dr.table->chunks.size() * dr.ninst;
         nmats += (uint64_t)m->prims.size() * (dr.tex_override.empty() ? 1 : dr.ninst);
-        tris_in += m->ntris_visible * dr.ninst;
+        tris_in += dr.table->ntris_visible * dr.ninst;
     }
     // a (triangle, bin) entry is the 32-bit submission order chunk * 128 + slot, and the visibility key stores order + 1:
     // fewer than 2^25 - 1 chunks (2 G triangles) per frame
@@ -1581,7 +1650,7 @@ static int32_t run_frame(mtr_frame* f) {
         // interleaved bins: a chunk's rectangle holds a bin of every rank as soon as it is `world` bins wide, so there
         // is next to nothing to cull (and the work list would only cost): culling is for bands and super-tiles
         fb.own.cull = (d->cull_enabled && t.map != MTR_OWN_INTERLEAVED) ? 1u : 0u;
-        if (const char* e = getenv("MTR_CULL_DEBUG")) fb.own.cull = (uint32_t)strtol(e, nullptr, 10);  // timing ablations only
+        if (fb.own.cull && d->cull_debug != 0xFFFFFFFFu) fb.own.cull = d->cull_debug;  // timing ablations only (MTR_CULL_DEBUG at device creation)
     }
     else if (d->cull_unsharded && d->cull_enabled) {
         fb.own.cull = 1u;  // world 1: "a bin of this rank" = a bin of the target, so what is culled is what is off the target
@@ -1622,8 +1691,9 @@ static int32_t run_frame(mtr_frame* f) {
             const mtr_model* m = dr.model;
             const bool sk = dr.d_palettes && dr.npal;
             // one 16-bit mask per (instance slot, group of 16 chunks)
-            const uint64_t nx = ((uint64_t)m->chunks.size() + 15) / 16;
-            if (nx * 4 * dr.ninst > 0x7FFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
+            const uint64_t nx = ((uint64_t)dr.table->chunks.size() + 15) / 16;
+            // one-dimensional launch of nx * 4 * slots workgroups of 256 threads: HIP rejects 2^32 threads or more per dimension
+            if (nx * 4 * dr.ninst > 0xFFFFFFull) return fail(d, MTR_E_OVERFLOW, "too many geometry chunks in one sharded draw");
             work_off[di] = (uint32_t)work_total;
             work_total += (nx * dr.ninst + 1) & ~1ull;  // even: k_geom reads a mask through the aligned dword that holds it
             if (!dr.d_model_mats) continue;  // a single model: chunk culling only
@@ -1667,17 +1737,18 @@ static int32_t run_frame(mtr_frame* f) {
         Draw& dr = f->draws[di];
         mtr_model* m = dr.model;
         GeomParams gp{};
-        gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = m->d_chunks;
+        gp.vbuf = m->d_vbuf; gp.ibuf = m->d_ibuf; gp.prims = m->d_prims; gp.chunks = dr.table->d_chunks;
         gp.boxes = m->d_boxes;
-        gp.nchunks = (uint32_t)m->chunks.size(); gp.ninst = dr.ninst;
+        gp.nchunks = (uint32_t)dr.table->chunks.size(); gp.ninst = dr.ninst;
         if (dr.batch) { dr.batch->last_frame = this_frame; dr.batch->used = true; }
         if (dr.pal_ready) {  // uploads of a model palette (ring) or of a batch, made on the copy stream
             HIPCHK(d, hipStreamWaitEvent(sg, dr.pal_ready, 0));
             if (dr.pal_slot >= 0 && (size_t)dr.pal_slot < m->pal_ring.size()) {
                 mtr_model::PalBuf& pb = m->pal_ring[(size_t)dr.pal_slot];
-                pb.last_frame = this_frame;
+                pb.last_frame = this_frame;  // protects the buffer while this run's kernels are in flight
                 pb.used = true;
-                if (dr.pal_pinned) { pb.pinned--; dr.pal_pinned = false; }  // from here on last_frame protects it
+                // the pin stays: until the frame's overflow flags have been looked at it may be re-run (settle_frame, by
+                // mtr_frame_wait or the exchange thread, several submits later) and must then skin with the SAME palette
             }
         }
         gp.model_mats = dr.d_model_mats; gp.palettes = dr.d_palettes; gp.npal = dr.d_palettes ? dr.npal : 0;
@@ -1700,9 +1771,10 @@ static int32_t run_frame(mtr_frame* f) {
                 cp.work_mask = sl.work_mask + work_off[di]; cp.strad = sl.inst_list + strad_base + inst_off[di]; cp.nchunks = gp.nchunks;
                 cp.counters = fb.counters;
                 mtr_launch_cull_instances(cp, sg);
+                HIPCHK(d, hipGetLastError());  // a rejected launch must not pass as an empty frame (a later successful call clears the error)
             }
             ChunkCullParams cc{};
-            cc.chunks = m->d_chunks; cc.boxes = m->d_boxes; cc.nchunks = gp.nchunks; cc.ninst = dr.ninst;
+            cc.chunks = dr.table->d_chunks; cc.boxes = m->d_boxes; cc.nchunks = gp.nchunks; cc.ninst = dr.ninst;
             cc.inst_list = inst_cnt ? sl.inst_list + inst_off[di] : nullptr; cc.inst_count = inst_cnt;
             cc.strad = inst_cnt ? sl.inst_list + strad_base + inst_off[di] : nullptr;
             cc.model_mats = dr.d_model_mats; cc.palettes = gp.palettes; cc.npal = gp.npal; cc.pal_stride = gp.pal_stride;
@@ -1712,18 +1784,21 @@ static int32_t run_frame(mtr_frame* f) {
             cc.work_mask = sl.work_mask + work_off[di];
             cc.keep_all = (fb.own.cull == 3u || fb.own.cull == 4u) ? 1u : 0u;
             mtr_launch_cull_chunks(cc, sg);
+            HIPCHK(d, hipGetLastError());
             gp.work_mask = cc.work_mask; gp.work_nx = (gp.nchunks + 15u) / 16u;
             gp.inst_list = cc.inst_list; gp.inst_count = cc.inst_count;
         }
+        gp.slots_override = d->geom_slots;
         mtr_launch_geom(gp, sg);
+        HIPCHK(d, hipGetLastError());
         chunk_base += gp.nchunks * dr.ninst;
     }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[1], sg));
     // single-pass binning launches neither kernel: no event either (an event costs the stream ~5 us, which would count
     // as frame latency); mtr_frame_wait reports both stages as 0
-    if (!fb.direct) mtr_launch_scan(fb, sg);
+    if (!fb.direct) { mtr_launch_scan(fb, sg); HIPCHK(d, hipGetLastError()); }
     if (prof && !fb.direct) HIPCHK(d, hipEventRecord(f->ev[2], sg));
-    if (!fb.direct) mtr_launch_fill(fb, (uint32_t)total_chunks, sg);
+    if (!fb.direct) { mtr_launch_fill(fb, (uint32_t)total_chunks, sg); HIPCHK(d, hipGetLastError()); }
     if (prof && !fb.direct) HIPCHK(d, hipEventRecord(f->ev[3], st));
     TileParams tp{};
     tp.fb = fb; tp.mats = sl.mats; tp.color = f->fb.color; tp.depth = f->fb.depth;
@@ -1756,8 +1831,8 @@ static int32_t run_frame(mtr_frame* f) {
         sl.ctr_clean_draws = (uint32_t)ndraws;  // what a frame with more draws than this one finds beyond is stale
     }
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
-    if (use_vis || mixed) mtr_launch_tile_vis(tp, any_textured, st);
-    if (!use_vis) mtr_launch_tile(tp, any_textured, st);
+    if (use_vis || mixed) { mtr_launch_tile_vis(tp, any_textured, st); HIPCHK(d, hipGetLastError()); }
+    if (!use_vis) { mtr_launch_tile(tp, any_textured, st); HIPCHK(d, hipGetLastError()); }
     // a rank without a bin launches no tile workgroup: nobody else would publish the (clean) status
     if (fb.own.own_count == 0) __atomic_store_n(&d->status_host[sidx], 0x80000000u, __ATOMIC_RELEASE);
     if (prof) HIPCHK(d, hipEventRecord(f->ev[4], st));
@@ -1813,6 +1888,7 @@ static int32_t settle_frame(mtr_frame* f, bool wait_done) {
         {
             std::lock_guard<std::mutex> g(d->submit_mu);
             if (d->status_owner[f->status_idx] == f->frame_index) d->status_checked[f->status_idx] = true;
+            if (!flags) release_palette_pins(f);  // this frame will not run again
         }
         f->flags_checked = true;
         if (!flags) return MTR_OK;
@@ -2055,6 +2131,14 @@ int32_t mtr_frame_read_bin_counts(mtr_frame* f, uint32_t* entries, uint32_t* seg
         HIPCHK(d, hipMemcpyAsync(bf.data(), sl.bin_count, nbins * 8, hipMemcpyDeviceToHost, d->stream));
         HIPCHK(d, hipStreamSynchronize(d->stream));
         for (size_t b = 0; b < nbins; b++) { entries[b] = (uint32_t)bf[b]; segments[b] = (uint32_t)(bf[b] >> 32); }
+        if (f->own && f->shard_world > 1) {
+            // only the tile workgroups of the rank's own bins park a count: the words of the other bins hold whatever an
+            // earlier frame on this slot left there
+            std::vector<uint8_t> mine(nbins, 0);
+            for (uint32_t k = f->own->offs[f->shard_rank]; k < f->own->offs[f->shard_rank + 1]; k++) mine[f->own->lists[k]] = 1;
+            for (size_t b = 0; b < nbins; b++)
+                if (!mine[b]) entries[b] = segments[b] = 0;
+        }
         return MTR_OK;
     }
     for (size_t b = 0; b < nbins; b++) { entries[b] = bs[b + 1] - bs[b]; segments[b] = ss[b + 1] - ss[b]; }
@@ -2113,25 +2197,34 @@ static void exchange_main(mtr_device* d, Exchange* x) {
         int32_t rc;
         { std::lock_guard<std::mutex> g(x->mu); rc = x->err; }
         std::string msg;
+        // NO RANK MAY SKIP A COLLECTIVE.  The all-gather of frame k completes only when every rank has issued it: a rank
+        // that failed (this frame, or an earlier one whose error has not been collected yet) still takes part, sending a
+        // shard filled with the frame's clear colour, and carries its status out of band -- mtr_device_exchange_drain
+        // returns it, and the host agrees on it across the ranks (bench.py: a MIN all-reduce after the drain).  Skipping
+        // the call instead would leave the healthy ranks waiting in frame k's collective for ever.
+        const Exchange::Lane ln = x->lanes[(size_t)(x->dealt++ % x->lanes.size())];
+        // every rank sends exactly its shard of THIS frame: the unpack derives the per-rank stride from the frame size
+        const size_t count = mtr_frame_shard_bytes(f);
         if (rc == MTR_OK) {
-            const Exchange::Lane ln = x->lanes[(size_t)(x->dealt++ % x->lanes.size())];
             // a frame whose bin queues overflowed is re-run (exact two-pass queues) BEFORE its colour is packed: the
             // gathered frame is never missing triangles.  The flags are known when the frame's tile kernel starts, so
             // in the normal case this does not wait for the frame to finish.
             rc = settle_frame(f, false);
-            // every rank sends exactly its shard of THIS frame: the unpack derives the per-rank stride from the frame size
-            const size_t count = mtr_frame_shard_bytes(f);
             if (rc == MTR_OK) rc = mtr_frame_pack_color_shard_on_stream(f, ln.send, count, ln.stream);
-            if (rc != MTR_OK) {
-                { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
-            } else {
-                const int nrc = x->fn(ln.send, ln.gathered, count, x->dtype_u8, ln.comm, ln.stream);
-                if (nrc != 0) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
-            }
-            if (rc == MTR_OK) {
-                rc = mtr_frame_unpack_color_shards_on_stream(f, ln.gathered, ln.dst, ln.stream);
-                if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
-            }
+            if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
+        }
+        if (rc != MTR_OK) {  // the shard of a rank in error: the clear colour (count is a multiple of 4)
+            std::vector<uint32_t> fill(count / 4, f->clear_rgba8);
+            (void)hipMemcpyAsync(ln.send, fill.data(), count, hipMemcpyHostToDevice, ln.stream);
+            (void)hipStreamSynchronize(ln.stream);  // `fill` goes out of scope
+        }
+        {
+            const int nrc = x->fn(ln.send, ln.gathered, count, x->dtype_u8, ln.comm, ln.stream);
+            if (nrc != 0 && rc == MTR_OK) { rc = MTR_E_HIP; msg = "all-gather callback returned " + std::to_string(nrc); }
+        }
+        if (rc == MTR_OK) {
+            rc = mtr_frame_unpack_color_shards_on_stream(f, ln.gathered, ln.dst, ln.stream);
+            if (rc != MTR_OK) { std::lock_guard<std::mutex> g(g_err_mu); msg = d->err; }
         }
         mtr_frame_destroy(f);
         {

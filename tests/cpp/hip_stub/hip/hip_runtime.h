@@ -22,7 +22,10 @@ enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 
 inline const char* hipGetErrorString(hipError_t) { return "stub"; }
-inline hipError_t hipGetLastError() { return hipSuccess; }
+// tests inject a launch failure: the next hipGetLastError() of the SAME thread reports (and clears) it
+inline int& hipStubInjectedError() { static thread_local int e = 0; return e; }
+inline hipError_t hipGetLastError() { const int e = hipStubInjectedError(); hipStubInjectedError() = 0; return e; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 template <class T>

@@ -239,8 +239,8 @@ def test_bin_counts_of_empty_bins_are_zero_whatever_the_buffer_held(gpu_device):
 @pytest.mark.parametrize("slots", ["1", "5"])
 def test_instances_beyond_the_full_rate_launch_take_the_slow_exact_path(gpu_device, slots, monkeypatch):
     """the geometry launch of a sharded batch covers twice the rank's fair share of instance slots at full rate and the
-    rest through k_geom_rest (one workgroup per slot); MTR_GEOM_SLOTS shrinks the first part so that most of the kept
-    instances take the second: same pixels, same counts, every queue builder and tile kernel"""
+    rest through k_geom_rest (one workgroup per slot); MTR_GEOM_SLOTS (read once, at device creation) shrinks the first
+    part so that most of the kept instances take the second: same pixels, same counts, every queue builder and tile kernel"""
     from mt_renderer_amd import api
     w, h = 640, 360
     small = scene.skinned_capsule_model([((0.0, 0.0, 0.0), 0.35, 1.6)], rows=24, cols=40)
@@ -251,12 +251,17 @@ def test_instances_beyond_the_full_rate_launch_take_the_slow_exact_path(gpu_devi
     owner = sharding.owner_map(w, h, 3, sharding.BANDS)
     ref = {r: render_gpu(gpu_device, w, h, draws, shard=(r, 3, sharding.BANDS)) for r in range(3)}
     monkeypatch.setenv("MTR_GEOM_SLOTS", slots)
-    for rank in range(3):
-        part = render_gpu(gpu_device, w, h, draws, shard=(rank, 3, sharding.BANDS))  # all builders x both tile kernels inside
-        own = owner == rank
-        assert (part[0][own] == full[0][own]).all() and (part[1].view(np.uint32)[own] == full[1].view(np.uint32)[own]).all(), rank
-        for key in ("tris_setup", "bin_entries", "chunks_culled"):
-            assert part[2][key] == ref[rank][2][key], (rank, key)
+    dev = api.Device(0)  # a device of its own: the hook is not read in the submit path
+    monkeypatch.delenv("MTR_GEOM_SLOTS")
+    try:
+        for rank in range(3):
+            part = render_gpu(dev, w, h, draws, shard=(rank, 3, sharding.BANDS))  # all builders x both tile kernels inside
+            own = owner == rank
+            assert (part[0][own] == full[0][own]).all() and (part[1].view(np.uint32)[own] == full[1].view(np.uint32)[own]).all(), rank
+            for key in ("tris_setup", "bin_entries", "chunks_culled"):
+                assert part[2][key] == ref[rank][2][key], (rank, key)
+    finally:
+        dev.close()
 
 
 def test_unsharded_frames_can_cull_what_is_off_the_target(gpu_device):

@@ -38,3 +38,20 @@ def test_exchange_thread_under_thread_sanitizer(tmp_path):
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
     assert int(r.stdout.strip().split("=")[1]) > 2500
+
+
+def test_no_rank_skips_a_collective_under_thread_sanitizer(tmp_path):
+    """two ranks (two devices, an exchange thread each) joined by an all-gather that completes only when both have issued it;
+    rank 1's pack fails at one frame, "overflowed" frames are re-run by the exchange threads while the render threads flip
+    parts_disp and the palette of the model they draw.  No hang, as many all-gathers as frames on both ranks, the error
+    comes out of rank 1's drain (and of the MIN the host takes over the ranks), no data race (tests/cpp/exchange_ranks_tsan.cpp)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "exchange_ranks_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-w",
+                           "-I", os.path.join(ROOT, "tests", "cpp", "hip_stub"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "exchange_ranks_tsan.cpp"), "-o", exe, "-lz", "-pthread"])
+    r = subprocess.run([exe, "900"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
+    assert "handed=1800" in r.stdout and "agreed_status=4" in r.stdout and 'rank1_error="reported"' in r.stdout, r.stdout
