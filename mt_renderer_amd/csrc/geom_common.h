@@ -14,10 +14,12 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p, bool al4) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-// x / d for a small integer x: bit-identical to the IEEE division (tests/test_div_exact.py) in three instructions.
-// Off by default: on the headline scene it made k_geom slower (37.8 -> 41.9 us); MTR_DIV_FAST3 keeps it for A/B runs.
+// x / d for a small integer x: bit-identical to the IEEE division (tests/test_div_exact.py) in three instructions instead
+// of the ten of the IEEE expansion.  Seven of these per vertex (SNORM16 position, UNORM8 weights).  Rounds 1-2 measured it
+// slower in k_geom (the 80-VGPR allocation then spilled in the prologue); with the vertex stage feeding LDS instead of
+// living across the whole kernel it is the default.  -DMTR_DIV_IEEE restores the plain division for A/B runs.
 __device__ __forceinline__ float div_small(float x, float d, float r) {
-#ifdef MTR_DIV_FAST3
+#ifndef MTR_DIV_IEEE
     const float q0 = x * r;
     return fmaf(fmaf(-q0, d, x), r, q0);
 #else
@@ -74,6 +76,70 @@ __device__ __forceinline__ void decode_elem(uint32_t fmt, uint32_t cnt, const ui
         break;
     }
     default: break;
+    }
+}
+
+// The same table decoding an element that is already in registers (w0 = its first four bytes, w1, w2 the next eight;
+// little-endian): the vertex stage issues every load of a vertex first and decodes afterwards, so that a wave pays one
+// memory round trip per vertex instead of one per element (decode_elem waits for each element's load in turn).
+__device__ __forceinline__ void decode_regs(uint32_t fmt, uint32_t cnt, uint32_t w0, uint32_t w1, uint32_t w2, float& x, float& y, float& z) {
+    x = 0.0f; y = 0.0f; z = 0.0f;
+    switch (fmt) {
+    case 10: /* U8N */
+    case 13: /* U8NL */
+        x = unorm8f(w0); y = unorm8f(w0 >> 8);
+        if (!(fmt == 10 && cnt == 1)) z = unorm8f(w0 >> 16);
+        break;
+    case 9: /* S8N */
+        x = snorm8f(w0 & 0xff); y = snorm8f((w0 >> 8) & 0xff);
+        if (cnt != 1) z = snorm8f((w0 >> 16) & 0xff);
+        break;
+    case 5: /* S16N */
+        x = snorm16f(w0 & 0xffff); y = snorm16f(w0 >> 16);
+        if (cnt == 3) z = snorm16f(w1 & 0xffff);
+        break;
+    case 2: /* F16 x2 */
+        x = half_bits_to_float(w0 & 0xffff); y = half_bits_to_float(w0 >> 16);
+        break;
+    case 1: /* F32 x3 */
+        x = __uint_as_float(w0); y = __uint_as_float(w1); z = __uint_as_float(w2);
+        break;
+    case 11: /* SCMP3N, opted into by MTR_ELEM_DECODE_SCMP3N: three signed 10-bit fields, max(v / 511, -1) */ {
+        const float fx = (float)((int32_t)(w0 << 22) >> 22) / 511.0f, fy = (float)((int32_t)(w0 << 12) >> 22) / 511.0f,
+                    fz = (float)((int32_t)(w0 << 2) >> 22) / 511.0f;
+        x = fx < -1.0f ? -1.0f : fx; y = fy < -1.0f ? -1.0f : fy; z = fz < -1.0f ? -1.0f : fz;
+        break;
+    }
+    default: break;
+    }
+}
+// bytes of an element the decode reads (host: elem_bytes in mtr_api.cpp); 0 for formats the table does not hold
+__device__ __forceinline__ uint32_t elem_nbytes(uint32_t fmt, uint32_t cnt) {
+    switch (fmt) {
+    case 10: return cnt == 1 ? 2u : 4u;
+    case 13: return 4u;
+    case 9: return cnt == 1 ? 2u : 4u;
+    case 5: return cnt == 1 ? 4u : 8u;
+    case 2: return 4u;
+    case 1: return 12u;
+    case 11: return 4u;
+    default: return 0u;
+    }
+}
+// the raw bytes of an element: up to three dwords, loads only (nothing waits here).  The vertex buffer is padded by 16
+// bytes on the device, so a whole-dword read of a 2-byte element at the end of the last vertex stays inside it.
+__device__ __forceinline__ void load_elem(const uint8_t* p, bool al4, uint32_t nbytes, uint32_t& w0, uint32_t& w1, uint32_t& w2) {
+    w0 = 0; w1 = 0; w2 = 0;
+    if (nbytes == 0) return;
+    if (al4) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+        w0 = q[0];
+        if (nbytes > 4) w1 = q[1];
+        if (nbytes > 8) w2 = q[2];
+    } else {
+        w0 = nbytes >= 4 ? ld32(p, false) : ld16(p);
+        if (nbytes > 4) w1 = ld32(p + 4, false);
+        if (nbytes > 8) w2 = ld32(p + 8, false);
     }
 }
 
@@ -141,16 +207,24 @@ __device__ __forceinline__ VOut shade_vertex(const uint8_t* vbuf, const DPrim& p
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ VOut shade_vertex_mfma(const uint8_t* vbuf, const DPrim& pr, uint32_t vid, bool active,
-                                                  const float (&M)[16], const float* s_pal, uint32_t npal, bool skinned) {
+                                                  const float* s_M, const float* s_pal, uint32_t npal, bool skinned, bool want_uv) {
     const uint32_t lane = threadIdx.x & 63, row = lane & 3;
     const bool al4 = pr.aligned4 != 0;
     float px = 0.0f, py = 0.0f, pz = 0.0f, tu = 0.0f, tv = 0.0f, tz;
     uint32_t jw = 0, ww = 0;
-    if (active) {
-        const uint8_t* vp = vbuf + pr.vertex_base + (size_t)vid * pr.stride;
-        decode_elem(pr.pos_fmt, pr.pos_cnt, vp + pr.pos_off, al4, px, py, pz);
-        if (pr.has_uv) decode_elem(pr.uv_fmt, pr.uv_cnt, vp + pr.uv_off, al4, tu, tv, tz);
-        if (skinned) { jw = ld32(vp + pr.joint_off, al4); ww = ld32(vp + pr.weight_off, al4); }
+    want_uv = want_uv && pr.has_uv;
+    {
+        // every load of the vertex first (element sizes are wave-uniform), decode once they are all on their way
+        uint32_t p0 = 0, p1 = 0, p2 = 0, u0 = 0, u1 = 0, u2 = 0;
+        if (active) {
+            const uint8_t* vp = vbuf + pr.vertex_base + (size_t)vid * pr.stride;
+            load_elem(vp + pr.pos_off, al4, elem_nbytes(pr.pos_fmt, pr.pos_cnt), p0, p1, p2);
+            if (want_uv) load_elem(vp + pr.uv_off, al4, elem_nbytes(pr.uv_fmt, pr.uv_cnt), u0, u1, u2);
+            if (skinned) { jw = ld32(vp + pr.joint_off, al4); ww = ld32(vp + pr.weight_off, al4); }
+        }
+        decode_regs(pr.pos_fmt, pr.pos_cnt, p0, p1, p2, px, py, pz);
+        if (want_uv) decode_regs(pr.uv_fmt, pr.uv_cnt, u0, u1, u2, tu, tv, tz);
+        // inactive lanes hold zero bits, which every format decodes to 0.0
     }
     float q0 = px, q1 = py, q2 = pz;
     if (skinned) {  // wave-uniform
@@ -191,13 +265,11 @@ __device__ __forceinline__ VOut shade_vertex_mfma(const uint8_t* vbuf, const DPr
             }
         }
     }
+    // clip = M * (q, 1): A = row (lane & 3) of the workgroup's matrix, straight from LDS (s_M: 16 floats, column-major)
     const float q[4] = {q0, q1, q2, 1.0f};
     v4f cl = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const float a = row == 0 ? M[c * 4 + 0] : row == 1 ? M[c * 4 + 1] : row == 2 ? M[c * 4 + 2] : M[c * 4 + 3];
-        cl = __builtin_amdgcn_mfma_f32_4x4x1f32(a, q[c], cl, 0, 0, 0);
-    }
+    for (int c = 0; c < 4; c++) cl = __builtin_amdgcn_mfma_f32_4x4x1f32(s_M[c * 4 + row], q[c], cl, 0, 0, 0);
     VOut r = {cl[0], cl[1], cl[2], cl[3], tu, tv};
     return r;
 }

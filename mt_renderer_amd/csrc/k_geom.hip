@@ -119,25 +119,22 @@ __device__ __forceinline__ VOut plane_lerp(const VOut& in, const VOut& out, floa
     return r;
 }
 
-__device__ __forceinline__ void compose_matrix(const GeomParams& P, uint32_t inst, float (&M)[16]) {
-    if (P.model_mats) {
-        const float* B = P.model_mats + (size_t)inst * 16;
+// + the instance's clip matrix M = view_proj * model, ONCE per workgroup: sixteen threads compute one element each (a k-ordered
+// fma chain from 0, like every contraction of the numeric contract) into s_M.  Every wave used to compose its own copy -- 32 packed fmas + 30 moves per
+// wave, 11 % of k_geom's VALU instructions on the instanced configs (PMC ablation, round 3) -- and then hold it in 16
+// VGPRs for the whole kernel; the vertex stage now reads the row it needs straight from LDS.
+__device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst, float* s_pal, float* s_M) {
+    if (threadIdx.x < 16) {
+        const uint32_t c = threadIdx.x >> 2, i = threadIdx.x & 3u;
+        float a = P.vp[threadIdx.x];
+        if (P.model_mats) {
+            const float* B = P.model_mats + (size_t)inst * 16;
+            a = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float a = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) a = fmaf(P.vp[k * 4 + i], B[c * 4 + k], a);
-                M[c * 4 + i] = a;
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) M[i] = P.vp[i];
+            for (int k = 0; k < 4; k++) a = fmaf(P.vp[k * 4 + i], B[c * 4 + k], a);
+        }
+        s_M[threadIdx.x] = a;
     }
-}
-
-__device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst, float* s_pal) {
     if (P.palettes && P.npal) {
         const float4* src = reinterpret_cast<const float4*>(P.palettes + (size_t)inst * P.pal_stride);
         for (uint32_t i = threadIdx.x; i < P.npal * 4; i += blockDim.x) reinterpret_cast<float4*>(s_pal)[i] = src[i];
@@ -149,31 +146,83 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
 // for frames the visibility-key tile kernel renders (no order kept, no segments)
 template <int MODE>
 __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, uint32_t c, const DChunk& ch, const DPrim& pr,
-                                           bool skinned, const float (&M)[16], const float* s_pal, RecHdr* s_hdr, uint32_t* s_slot,
-                                           uint32_t lane) {
+                                           bool skinned, const float* s_M, const float* s_pal, RecHdr* s_hdr, uint32_t* s_slot,
+                                           float4* s_pv, uint32_t lane) {
     const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
     const uint32_t mat = P.mat_base + inst * P.mat_inst_stride + ch.prim;
     const uint32_t W = P.fb.W, H = P.fb.H;
     const bool strip = pr.topology == 4;
+    const DMat dmat = P.mats[mat];  // wave-uniform
+    // texcoord planes are only read by textured materials: no registers, LDS or HBM traffic for them otherwise
+    const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
 
-    // ---- index fetch (Uint16, src/model.rs:307) ----
+    // ---- vertex stage, in RAIL order.  The matrix-core skinning needs the four lanes of a block to share their joint
+    //      indices (geom_common.h: shade_vertex_mfma).  In strip order neighbouring lanes alternate between the two rails of
+    //      the strip -- two rows of the mesh, which as often as not hang on different joints -- and every wave then also ran
+    //      the whole VALU fallback for its incoherent blocks: 128 of ~600 VALU instructions per chunk (PMC, C5).  So the
+    //      vertex stage runs permuted: shading lane s takes strip position pi(s) = the even positions first, then the odd
+    //      ones; a block is four consecutive vertices of ONE rail.  The projected vertices go through 1-2 KB of LDS private
+    //      to the wave (written at pi(s), read back at the lane's own position): no shuffle, no workgroup barrier.
+    //      Triangle lists keep the identity order. ----
+    const uint32_t sp = strip ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
+    {
+        // index fetch (Uint16, src/model.rs:307)
+        const int32_t ps = (int32_t)ch.start - 2 + (int32_t)sp;
+        const bool in_s = ps >= 0 && (uint32_t)ps < pr.index_num;
+        const uint32_t idx = in_s ? (uint32_t)P.ibuf[pr.index_ofs + (uint32_t)ps] : 0xFFFFu;
+        const bool restart_s = !in_s || (strip && idx == 0xFFFFu);
+        const uint32_t vid_s = idx + pr.index_base;  // base_vertex = index_base, src/model.rs:359
+        const bool valid_s = !restart_s && vid_s < pr.vertex_num;
+        // skinning + MVP on the matrix cores, wave-wide (all 64 lanes issue the MFMAs; invalid lanes carry zeros)
+#ifndef MTR_ABL  // instruction-count ablations (tools/abl_geom.sh): what each part of the kernel costs, by PMC difference
+#define MTR_ABL 0
+#endif
+#if MTR_ABL == 2   // no vertex shader at all
+        VOut v; v.x = (float)(vid_s & 1023u) * 0.001f - 0.5f; v.y = (float)(vid_s >> 10) * 0.01f - 0.3f; v.z = 0.5f; v.w = 1.0f; v.u = v.v = 0.0f;
+#else
+        const VOut v = shade_vertex_mfma(P.vbuf, pr, vid_s, valid_s, s_M, s_pal, P.npal, MTR_ABL == 1 ? false : skinned, want_b);
+#endif
+        PV q;
+        q.X = 0; q.Y = 0; q.z = 0.0f; q.iw = 0.0f; q.up = 0.0f; q.vp = 0.0f; q.flags = 0;
+        if (valid_s) {
+#if MTR_ABL == 6   // no projection
+            q.X = (int32_t)(v.x * 1000.0f); q.Y = (int32_t)(v.y * 1000.0f); q.z = v.z; q.flags = 2u;
+#else
+            q = project(v, W, H);
+#endif
+            q.flags |= 1u | (outcode(v) << 2);
+        }
+        // flags word: bits 0..7 PV flags, bit 8 restart, bits 16..31 the vertex id (valid ids are < 65536: vertex_num is 16 bits)
+        const uint32_t fw = q.flags | (restart_s ? 0x100u : 0u) | (vid_s << 16);
+        s_pv[sp] = make_float4(__int_as_float(q.X), __int_as_float(q.Y), q.z, __uint_as_float(fw));
+        if (want_b) s_pv[64 + sp] = make_float4(q.iw, q.up, q.vp, 0.0f);
+    }
+    // s_pv is private to this wave: no workgroup barrier, LDS ops of one wave are ordered
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int32_t p = (int32_t)ch.start - 2 + (int32_t)lane;
     const bool in_range = p >= 0 && (uint32_t)p < pr.index_num;
-    const uint32_t idx = in_range ? (uint32_t)P.ibuf[pr.index_ofs + (uint32_t)p] : 0xFFFFu;
-    const bool is_restart = !in_range || (strip && idx == 0xFFFFu);
-    const uint32_t vid = idx + pr.index_base;  // base_vertex = index_base, src/model.rs:359
-    const bool vvalid = !is_restart && vid < pr.vertex_num;
-
-    // ---- vertex stage ----
     PV me;
-    me.X = 0; me.Y = 0; me.z = 0.0f; me.iw = 0.0f; me.up = 0.0f; me.vp = 0.0f; me.flags = 0;
-    // skinning + MVP on the matrix cores, wave-wide (all 64 lanes issue the MFMAs; invalid lanes carry zeros)
-    const VOut v = shade_vertex_mfma(P.vbuf, pr, vid, vvalid, M, s_pal, P.npal, skinned);
-    if (vvalid) {
-        me = project(v, W, H);
-        me.flags |= 1u | (outcode(v) << 2);
+    me.iw = 0.0f; me.up = 0.0f; me.vp = 0.0f;
+    uint32_t vid;
+    bool is_restart;
+    {
+        const float4 a = s_pv[lane];
+        const uint32_t fw = __float_as_uint(a.w);
+        me.X = __float_as_int(a.x); me.Y = __float_as_int(a.y); me.z = a.z; me.flags = fw & 0xFFu;
+        is_restart = (fw & 0x100u) != 0;
+        vid = fw >> 16;
+        if (want_b) {
+            const float4 b = s_pv[64 + lane];
+            me.iw = b.x; me.up = b.y; me.vp = b.z;
+        }
     }
 
+#if MTR_ABL == 3   // vertex stage only
+    if (me.X == 0x7fffffff) P.fb.counters[CTR_OVERFLOW] = vid;  // keep the loads alive
+    return;
+#endif
     // ---- strip assembly: which lanes complete a triangle, and its winding parity ----
     const uint64_t R = __ballot(is_restart);
     const uint64_t below = R & ((1ull << lane) - 1ull);
@@ -191,13 +240,16 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     // lanes l-1 and l-2 by DPP wave_shr:1 (VALU moves instead of the 14 ds_bpermute behind __shfl_up; same speed in an
     // A/B run, tools/sweep_ab.sh, but the LDS pipe stays free for the palette reads)
     PV v1, v2;
+    v1.iw = v1.up = v1.vp = v2.iw = v2.up = v2.vp = 0.0f;
 #define MTR_SHR1(x) __builtin_amdgcn_update_dpp((int)(x), (int)(x), 0x138, 0xf, 0xf, false)
     v1.X = MTR_SHR1(me.X); v2.X = MTR_SHR1(v1.X);
     v1.Y = MTR_SHR1(me.Y); v2.Y = MTR_SHR1(v1.Y);
     v1.z = __int_as_float(MTR_SHR1(__float_as_int(me.z))); v2.z = __int_as_float(MTR_SHR1(__float_as_int(v1.z)));
-    v1.iw = __int_as_float(MTR_SHR1(__float_as_int(me.iw))); v2.iw = __int_as_float(MTR_SHR1(__float_as_int(v1.iw)));
-    v1.up = __int_as_float(MTR_SHR1(__float_as_int(me.up))); v2.up = __int_as_float(MTR_SHR1(__float_as_int(v1.up)));
-    v1.vp = __int_as_float(MTR_SHR1(__float_as_int(me.vp))); v2.vp = __int_as_float(MTR_SHR1(__float_as_int(v1.vp)));
+    if (want_b) {
+        v1.iw = __int_as_float(MTR_SHR1(__float_as_int(me.iw))); v2.iw = __int_as_float(MTR_SHR1(__float_as_int(v1.iw)));
+        v1.up = __int_as_float(MTR_SHR1(__float_as_int(me.up))); v2.up = __int_as_float(MTR_SHR1(__float_as_int(v1.up)));
+        v1.vp = __int_as_float(MTR_SHR1(__float_as_int(me.vp))); v2.vp = __int_as_float(MTR_SHR1(__float_as_int(v1.vp)));
+    }
     v1.flags = (uint32_t)MTR_SHR1(me.flags); v2.flags = (uint32_t)MTR_SHR1(v1.flags);
     const uint32_t vid1 = (uint32_t)MTR_SHR1(vid), vid2 = (uint32_t)MTR_SHR1(vid1);
 #undef MTR_SHR1
@@ -217,15 +269,21 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     const uint32_t f_and = ta.flags & tb.flags & tc.flags, f_or = ta.flags | tb.flags | tc.flags;
     tri = tri && (f_and & 1u);            // every vertex inside the bound slice (SPEC.md)
     tri = tri && ((f_and >> 2) == 0);     // trivial frustum reject
+#if MTR_ABL == 5   // no triangle set-up
+    tri = tri && ta.X == 0x7ffffff0;
+#endif
     if (tri) {
         if (!((f_or >> 2) & OC_ZN) && (f_and & 2u)) {
             if (setup_tri(ta, tb, tc, W, H, mat, pr.cull, r0)) n_out = 1;
         } else {
             // near-plane clip (z >= 0) and / or guard-band clip: rare, re-shades the three vertices in clip space
             const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
-            VOut cv[3] = {shade_vertex(P.vbuf, pr, ia, M, s_pal, P.npal, skinned),
-                          shade_vertex(P.vbuf, pr, ib, M, s_pal, P.npal, skinned),
-                          shade_vertex(P.vbuf, pr, ic, M, s_pal, P.npal, skinned)};
+            float M[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) M[i] = s_M[i];
+            VOut cv[3];
+#pragma nounroll
+            for (int i = 0; i < 3; i++) cv[i] = shade_vertex(P.vbuf, pr, i == 0 ? ia : (i == 1 ? ib : ic), M, s_pal, P.npal, skinned);
             int n = 3;
             if ((f_or >> 2) & OC_ZN) {
                 n = 0;
@@ -311,9 +369,6 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     }
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;
-    // texcoord planes are only read by textured materials: do not spend 48 B/triangle of HBM writes otherwise
-    const DMat dmat = P.mats[mat];  // wave-uniform
-    const bool want_b = pr.has_uv && dmat.shader == MTR_SH_TEXTURED;
     // a solid colour in the default depth state replaces the pixel whatever the blend (its alpha is 1): the fragment
     // stage finds the colour in the record itself, no dependent material lookup; everything else carries its material id
     const uint32_t solid = (dmat.shader != MTR_SH_TEXTURED && dmat.blend != MTR_DB_ADD && dmat.dstate == 3u) ? 1u : 0u;
@@ -354,6 +409,9 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+#if MTR_ABL == 4   // no binning
+    return;
+#endif
     // ---- triangle -> bin: DIRECT = single-pass binning straight into the bounded per-bin queues;
     //      otherwise count only (one non-returning atomic per (wave, bin) group), k_scan + k_fill follow ----
     for (uint32_t round = 0; round * 64 < total; ++round) {
@@ -386,6 +444,8 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
     __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
+    __shared__ float4 s_pv[4][128];                       // per wave: the projected vertices of its 64 strip positions (+ texcoords)
+    __shared__ float s_M[16];                             // the instance's clip matrix (stage_palette)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (!CULL) {  // one instance per blockIdx.y, nothing to test
@@ -396,13 +456,11 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
         const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
         const uint32_t c = blk * 4 + wave;
         if (blk >= nblk) return;  // whole workgroup
-        stage_palette(P, blockIdx.y, s_pal);  // every thread of the workgroup copies its share
+        stage_palette(P, blockIdx.y, s_pal, s_M);  // every thread of the workgroup copies its share
         if (c >= P.nchunks) return;
         const DChunk ch = P.chunks[c];
         const DPrim pr = P.prims[ch.prim];
-        float M[16];
-        compose_matrix(P, blockIdx.y, M);
-        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
         return;
     }
     // sharded: workgroup g = (group x, quarter q) fastest, then instance slot ii: it takes the q-th four survivors of the 16
@@ -425,7 +483,7 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     const uint32_t m16 = (mi & 1u) ? mword >> 16 : mword & 0xFFFFu;
     const uint32_t k = (uint32_t)__popc(m16);
     if (q * 4u >= k) return;
-    stage_palette(P, inst, s_pal);
+    stage_palette(P, inst, s_pal, s_M);
     const uint32_t nth = q * 4u + wave;  // this wave's survivor
     if (nth >= k) return;
     uint32_t mm = m16;
@@ -433,9 +491,7 @@ __global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
     const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
     const DChunk ch = P.chunks[c];
     const DPrim pr = P.prims[ch.prim];
-    float M[16];
-    compose_matrix(P, inst, M);
-    geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+    geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
 }
 
 // The instance slots the full-rate launch of k_geom<MODE, true> does not cover (mtr_launch_geom): MTR_GEOM_REST_SPLIT
@@ -449,6 +505,8 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
     __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];
+    __shared__ float4 s_pv[4][128];
+    __shared__ float s_M[16];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t split = min(P.work_nx, MTR_GEOM_REST_SPLIT);
@@ -456,9 +514,7 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
     const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
     if (ii >= nlive) return;
     const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
-    stage_palette(P, inst, s_pal);
-    float M[16];
-    compose_matrix(P, inst, M);
+    stage_palette(P, inst, s_pal, s_M);
     for (uint32_t x = blockIdx.x % split; x < P.work_nx; x += split) {
         const uint32_t m16 = P.work_mask[(size_t)ii * P.work_nx + x];
         const uint32_t k = (uint32_t)__popc(m16);
@@ -468,14 +524,14 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
             const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
             const DChunk ch = P.chunks[c];
             const DPrim pr = P.prims[ch.prim];
-            geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, M, s_pal, s_hdr[wave], s_slot[wave], lane);
+            geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
         }
     }
 }
 
 __device__ __forceinline__ void compose_vp_model(const float (&vp)[16], const float* model_mats, uint32_t inst, float (&M)[16]) {
     if (model_mats) {
-        const float* B = model_mats + (size_t)inst * 16;  // M = VP * Model, the chain of compose_matrix
+        const float* B = model_mats + (size_t)inst * 16;  // M = VP * Model, the fma chain of stage_palette
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -614,15 +670,14 @@ __global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCull
 // vertex stage alone (unit-parity hook: mtr_model_vertex_stage)
 __global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t prim, float* out_clip, float* out_uv) {
     extern __shared__ __align__(16) float s_pal[];
-    stage_palette(P, 0, s_pal);
-    float M[16];
-    compose_matrix(P, 0, M);
+    __shared__ float s_M[16];
+    stage_palette(P, 0, s_pal, s_M);
     const DPrim pr = P.prims[prim];
     const bool skinned = pr.skinnable && P.palettes && P.npal;
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     // whole waves call the MFMA path; the tail of the last wave is masked
     if ((v & ~63u) >= pr.vertex_num) return;
-    const VOut o = shade_vertex_mfma(P.vbuf, pr, v, v < pr.vertex_num, M, s_pal, P.npal, skinned);
+    const VOut o = shade_vertex_mfma(P.vbuf, pr, v, v < pr.vertex_num, s_M, s_pal, P.npal, skinned, true);
     if (v >= pr.vertex_num) return;
     out_clip[4 * v + 0] = o.x; out_clip[4 * v + 1] = o.y; out_clip[4 * v + 2] = o.z; out_clip[4 * v + 3] = o.w;
     out_uv[2 * v + 0] = o.u; out_uv[2 * v + 1] = o.v;

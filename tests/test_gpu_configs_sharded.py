@@ -165,6 +165,12 @@ def test_c5_full_size_remainder_kernel(monkeypatch):
     a = b = None
     try:
         a, b = _c5_scene(dev0, 32, 32), _c5_scene(dev1, 32, 32)
+        # the first frame of this scene on a fresh device overflows the default per-bin queue bound: it is re-run through
+        # the exact two-pass queues and the bound doubles for the frames that follow (tests/test_gpu_overflow.py)
+        for s in (a, b):
+            for _ in range(3):
+                first = s.render()
+        assert first[2]["binning"] == 1
         full = a.render()
         bands = a.balanced_bands(8)
         for rank in (3, 6):

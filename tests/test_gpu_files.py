@@ -169,3 +169,59 @@ def test_bind_pose_palette_from_the_file_skins_like_no_palette_at_all(gpu_device
     assert_same(got, ref, "model + joint cubes")
     assert got[2]["tris_in"] == md.input_triangles() + 64 * 12
     model.close(); mat.close(); sh.close()
+
+
+def test_sdl_tracks_drive_parts_disp_and_instances_of_gpu_frames(gpu_device):
+    """row f-2 end to end: a .sdl image (src/rscheduler.rs:119-210: BOOL / U32 / MATRIX / VECTOR / FLOAT tracks) is read,
+    its tracks are bound to parts_disp entries and to the instances of a batch, evaluated at three frame numbers
+    (mtr_rscheduler_apply), and what comes out drives Model::set_parts_disp and the batch of the GPU frame.  Every frame
+    equals the oracle's render of the same evaluated arrays; the three frames differ the way the tracks say."""
+    import copy
+    W, H = 480, 270
+    md = scene.skinned_capsule_model([((-0.45, 0.0, 0.0), 0.2, 1.2), ((0.0, 0.0, 0.0), 0.2, 1.2), ((0.45, 0.0, 0.0), 0.2, 1.2)], rows=16, cols=24)
+    w = md.prims.view(np.uint32).reshape(-1, 14)
+    w[:, 1] = (w[:, 1] & ~np.uint32(0xFFF)) | np.arange(3, dtype=np.uint32)  # one part per capsule (PrimitiveInfo::parts_no)
+    base, pals = scene.instance_lattice(3, 1)
+    base = base.astype(np.float32)
+    moved = base[1].copy(); moved[12] += np.float32(0.3); moved[13] -= np.float32(0.2); moved[0] *= np.float32(0.8)
+    p0 = tuple(float(v) for v in base[0, 12:15]) + (0.0,)
+    p1 = (p0[0] - 0.25, p0[1] + 0.3, p0[2], 0.0)
+    tracks = [dict(type=1, name="root"),
+              dict(type=11, prop=files.PROP_BOOL, name="PartsDisp1", keys=[(0, 0, True), (10, 0, False), (20, 0, True)]),
+              dict(type=6, prop=files.PROP_U32, name="PartsDisp2", keys=[(15, 0, 0)]),
+              dict(type=16, prop=22, name="Inst1Matrix", keys=[(0, 0, tuple(float(v) for v in base[1])), (12, 0, tuple(float(v) for v in moved))]),
+              dict(type=8, prop=21, name="Inst0Pos", keys=[(0, 0, p0), (18, 0, p1)]),
+              dict(type=9, prop=files.PROP_F32, name="Inst2Y", keys=[(5, 0, float(base[2, 13]) + 0.35)])]
+    sf = files.SchedulerFile(mt_files.write_rscheduler(tracks))
+    T = files
+    bindings = [(sf.find_track("PartsDisp1"), T.SDL_PARTS_DISP, 1), (sf.find_track("PartsDisp2"), T.SDL_PARTS_DISP, 2),
+                (sf.find_track("Inst1Matrix"), T.SDL_INSTANCE_MATRIX, 1), (sf.find_track("Inst0Pos"), T.SDL_INSTANCE_TRANSLATION, 0),
+                (sf.find_track("Inst2Y"), T.SDL_INSTANCE_TRANSLATE_Y, 2)]
+    vp = scene.to_f32_colmajor(scene.reference_view_proj(W, H))
+    model = api.Model.new(gpu_device, md)
+    seen = []
+    try:
+        for frame_no, want_pd in ((0, [1, 1, 1]), (13, [1, 0, 1]), (25, [1, 1, 0])):
+            pd = np.ones(3, dtype=np.uint8)
+            mm = base.copy()
+            sf.apply(frame_no, bindings, pd, mm)
+            assert list(pd) == want_pd, frame_no
+            model.set_parts_disp(pd)
+            batch = api.Batch(gpu_device, model, mm, pals)
+            fr = api.Frame(gpu_device, W, H)
+            fr.draw_batch(batch, vp)
+            fr.end()
+            got = (fr.color(), fr.depth(), fr.stats())
+            fr.close(); batch.close()
+            md_f = copy.copy(md)
+            md_f.parts_disp = pd.copy()
+            assert_same(got, render_oracle(W, H, [dict(md=md_f, vp=vp, model_mats=mm, palettes=pals)]), f".sdl frame {frame_no}")
+            assert got[2]["tris_in"] == 3 * int(pd.sum()) * (md.input_triangles() // 3)
+            seen.append((mm.copy(), got[0]))
+        assert (seen[0][0][1] == base[1]).all() and (seen[1][0][1] == moved).all()            # MATRIX key at 12
+        assert tuple(seen[1][0][0, 12:15]) == p0[:3] and tuple(seen[2][0][0, 12:15]) == tuple(np.float32(v) for v in p1[:3])  # VECTOR key at 18
+        assert seen[0][0][2, 13] == base[2, 13] and seen[1][0][2, 13] == np.float32(float(base[2, 13]) + 0.35)  # FLOAT key at 5
+        assert (seen[0][1] != seen[1][1]).any() and (seen[1][1] != seen[2][1]).any()
+    finally:
+        model.close()
+        sf.close()
