@@ -424,19 +424,8 @@ __device__ __forceinline__ bool clipbox_all_in_rank(const ClipBox& u, const Fram
     return rect_owned_all(fb.own, min(by0, fb.nby - 1u), by1);
 }
 
-// wave-wide union of the lanes' intervals (lanes that hold none pass lo = +inf, hi = -inf); every lane gets the result
-__device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f32(float v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-    return v;
-}
-// the same inside each row of 16 lanes (DPP rotations; min / max are idempotent, so every lane of a row ends up with
-// the row's result): one wave bounds four chunks at once, a chunk has <= 16 boxes
+// union of intervals inside each row of 16 lanes (DPP rotations; min / max are idempotent, so every lane of a row ends up
+// with the row's result): one wave bounds four chunks at once, a chunk has <= 16 boxes
 __device__ __forceinline__ float row_min_f32(float v) {
 #define MTR_ROR(x, c) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), c, 0xf, 0xf, false))
     v = fminf(v, MTR_ROR(v, 0x128)); v = fminf(v, MTR_ROR(v, 0x124)); v = fminf(v, MTR_ROR(v, 0x122)); v = fminf(v, MTR_ROR(v, 0x121));
@@ -446,6 +435,20 @@ __device__ __forceinline__ float row_max_f32(float v) {
     v = fmaxf(v, MTR_ROR(v, 0x128)); v = fmaxf(v, MTR_ROR(v, 0x124)); v = fmaxf(v, MTR_ROR(v, 0x122)); v = fmaxf(v, MTR_ROR(v, 0x121));
 #undef MTR_ROR
     return v;
+}
+// wave-wide union of the lanes' intervals (lanes that hold none pass lo = +inf, hi = -inf); every lane gets the result:
+// the row reduction, then the four rows' results through v_readlane (six ds_bpermute shuffles per value did this before)
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = row_min_f32(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = row_max_f32(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(64) void k_cull_instances(CullParams P) {
         const uint32_t nx = (P.nchunks + 15u) / 16u, tail = P.nchunks & 15u;
         for (uint32_t x = lane; x < nx; x += 64) P.work_mask[(size_t)slot * nx + x] = (uint16_t)((x == nx - 1u && tail) ? (1u << tail) - 1u : 0xFFFFu);
     }
-    if (P.comp) {  // what the chunk tests of this instance read (k_cull_chunks)
+    if (P.comp && !inside) {  // what the chunk tests of this instance read (k_cull_chunks tests the straddlers only)
         CompMat* out = P.comp + (size_t)inst * P.ncomp;
         for (uint32_t j = lane; j < P.ncomp; j += 64) out[j] = make_comp((have_pal && j + 1 < P.ncomp) ? pal + (size_t)j * 16 : nullptr, M);
     }
@@ -697,6 +697,9 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
         // every one of them leaves at once; when a rank does keep more, they are exact and only a little slower.
         uint32_t slots = p.ninst;
         if (p.inst_count && p.fb.own.world > 1) slots = std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world + 64u);  // 64 more cost 3 us
+        // the second launch costs ~4 us of stream time even when every one of its workgroups leaves at once: when the slots it
+        // would cover are few (idle workgroups at ~0.2 ns each: 20 000 of them = 4 us), the full-rate launch takes them all
+        if ((uint64_t)(p.ninst - slots) * p.work_nx * 4u <= 20000u) slots = p.ninst;
         if (p.slots_override) slots = std::min<uint32_t>(p.ninst, p.slots_override);  // MTR_GEOM_SLOTS at device creation: tests force the second launch
         dim3 grid(p.work_nx * 4u * slots);  // the host checked work_nx * 4 * ninst against the launch limit (2^32 threads)
         if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);

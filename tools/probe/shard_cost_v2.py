@@ -3,6 +3,7 @@ frames in flight (the bench's submission pattern).  A job of N ranks runs at the
 figure that matters is max over ranks; `bound` is what 0.85 per-GPU efficiency leaves a rank: t(N=1) / (0.85 N).
 
     python tools/probe/shard_cost_v2.py [headline|c4|c5|all] [out.json]
+    MTR_PROBE_MAPS=bands-balanced,bands-equal   restricts the ownership maps; MTR_PROBE_WORLDS=8 the world sizes
 """
 import json
 import os
@@ -66,9 +67,13 @@ def run(name, W, H, draw, nframes):
     print(f"{name}: N=1 {t1*1e6:.1f} us/frame, {st1['tris_setup']} triangles set up, {st1['bin_entries']} entries, serial geom {st1['geom_us']:.1f} tile {st1['tile_us']:.1f} us", flush=True)
     rw = row_weights(unsharded, W, H)
     res = {"n1_us": t1 * 1e6, "maps": {}}
+    only_maps = [m for m in os.environ.get("MTR_PROBE_MAPS", "").split(",") if m]
+    worlds = [int(w) for w in os.environ.get("MTR_PROBE_WORLDS", "2,4,8").split(",")]
     for map_name, own_map, param, balanced in (("interleaved", sharding.INTERLEAVED, 0, False), ("bands-equal", sharding.BANDS, 0, False),
                                                ("bands-balanced", sharding.BANDS, 0, True), ("supertiles8", sharding.SUPERTILES, 3, False)):
-        for world in (2, 4, 8):
+        if only_maps and map_name not in only_maps:
+            continue
+        for world in worlds:
             bands = sharding.balanced_bands(rw, world) if balanced else None
             per_rank = []
             for rank in range(world):
