@@ -372,7 +372,10 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     // a solid colour in the default depth state replaces the pixel whatever the blend (its alpha is 1): the fragment
     // stage finds the colour in the record itself, no dependent material lookup; everything else carries its material id
     const uint32_t solid = (dmat.shader != MTR_SH_TEXTURED && dmat.blend != MTR_DB_ADD && dmat.dstate == 3u) ? 1u : 0u;
-    const uint32_t mflags = solid | ((dmat.blend != MTR_DB_OFF ? 1u : 0u) << 8) | (dmat.translucent << 16);
+    // hard: the pixel depends on the order of ALL its fragments (additive blend, depth write or test off); a translucent
+    // material that is not hard depends only on the fragments that pass the depth test, which prefix minima of z identify
+    const uint32_t hard = (dmat.blend == MTR_DB_ADD || dmat.dstate != 3u) ? 1u : 0u;
+    const uint32_t mflags = solid | ((dmat.blend != MTR_DB_OFF ? 1u : 0u) << 8) | (dmat.translucent << 16) | (hard << 17);
     r0.a.pad0 = dmat.rgba8; r0.a.pad1 = mflags;
     r1.a.pad0 = dmat.rgba8; r1.a.pad1 = mflags;
     auto put_rec = [&](uint32_t slot, const Rec& r) {

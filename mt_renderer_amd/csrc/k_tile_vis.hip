@@ -21,6 +21,18 @@
 // frame is eligible (mtr_api.cpp); tests run both kernels on the same scenes.
 // VIS_WAVES waves per 16x16 bin (passes dealt round-robin, two workgroup barriers in total), no segment
 // sort (the submission order rides in the entry).
+//
+// STAIR (frames with translucent materials, round 3): alpha blending in the default depth state (test LessEqual + write)
+// depends on submission order only through the fragments that PASS the depth test, and those are exactly the prefix
+// minima of z in submission order: fragment f passes iff z_f <= z_e for every earlier fragment e of the pixel (a
+// fragment that fails leaves the depth buffer alone, so the depth f meets is the minimum over all its predecessors).
+// The set is order-independent to build: next to the max key each pixel keeps a short list of submission orders; a
+// fragment is appended unless the key it meets proves it dominated (an EARLIER fragment that is STRICTLY nearer -- with
+// entries arriving roughly in order that leaves little more than the prefix minima themselves).  The resolve walks a
+// pixel's list in increasing order, recomputes z from the record, keeps the running minimum, and shades + blends the
+// fragments that pass -- the ordered kernel's arithmetic, without its segment sort, ordered passes and per-pass set-up
+// (C5 with translucent textures: tile stage 675 -> see DESIGN.md).  A bin with a HARD order-dependent triangle (additive
+// blend, depth write or test off) or a pixel whose list overflows is flagged and left to the ordered kernel.
 #include "tile_common.h"
 
 namespace mtr {
@@ -97,6 +109,23 @@ __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t b
     s.chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
 }
 
+#define STAIR_K 8u  // submission orders kept per pixel (STAIR)
+
+// one fragment that passed coverage and the z range.  STAIR: also remember its order unless the key it meets proves it
+// dominated: `old` is SOME fragment of this pixel; if it is earlier and strictly nearer, this one fails the depth test
+// whatever else arrives (the depth it meets is <= z_old < z).
+template <bool STAIR>
+__device__ __forceinline__ void put_fragment(unsigned long long* s_key, uint32_t* s_cnt, uint32_t* s_list, uint32_t pix, unsigned long long key) {
+    if (!STAIR) {
+        atomicMax(&s_key[pix], key);
+        return;
+    }
+    const unsigned long long old = atomicMax(&s_key[pix], key);
+    if (old != 0ull && (uint32_t)old < (uint32_t)key && (uint32_t)(old >> 32) > (uint32_t)(key >> 32)) return;
+    const uint32_t slot = atomicAdd(&s_cnt[pix], 1u);
+    if (slot < STAIR_K) s_list[pix * STAIR_K + slot] = (uint32_t)key;
+}
+
 __device__ __forceinline__ unsigned long long make_key(float z, uint32_t ordk) {
     // 0 <= z <= 1 and z is never -0 (SPEC.md: vertex z comes from an fma chain started at +0), so the bit
     // pattern is monotonic; larger key = nearer, then later
@@ -105,7 +134,7 @@ __device__ __forceinline__ unsigned long long make_key(float z, uint32_t ordk) {
 
 // deferred textured shading of the winner at pixel (px,py): SPEC.md section 7, same operations as the
 // per-fragment path (the quad neighbours are evaluated from the same triangle's plane equations)
-__device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b, const DMat& mat, int32_t px, int32_t py) {
+__device__ __forceinline__ void sample_textured(const RecA& a, const RecB& b, const DMat& mat, int32_t px, int32_t py, float (&src)[4]) {
     const long long A2 = (long long)(a.X2 - a.X0) * (long long)(a.Y1 - a.Y0) - (long long)(a.X1 - a.X0) * (long long)(a.Y2 - a.Y0);
     const float rcpA = 1.0f / (float)A2;
     const float diw1 = b.iw1 - b.iw0, diw2 = b.iw2 - b.iw0, dup1 = b.up1 - b.up0, dup2 = b.up2 - b.up0,
@@ -130,9 +159,23 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
     const float dudx = (px & 1) ? u - uh : uh - u, dvdx = (px & 1) ? v - vh : vh - v;
     const float dudy = (py & 1) ? u - uw : uw - u, dvdy = (py & 1) ? v - vw : vw - v;
     const TexRef tr = {mat.tex, mat.tw, mat.th, mat.tlevels};
-    float src[4];
     sample_texture(tr, u, v, filter_select(dudx, dvdx, dudy, dvdy, mat.tw, mat.th, mat.tlevels), src);
+}
+__device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b, const DMat& mat, int32_t px, int32_t py) {
+    float src[4];
+    sample_textured(a, b, mat, px, py, src);
     return blend_store(0u, src, 0u);  // order-free: blending is off, or the texture is opaque (a == 1 exactly) and the blend a replace
+}
+// z of the record's triangle at the centre of pixel (px, py): the edge values are the exact integers the rasteriser
+// compares, so this is the float the flattened walk computed from its bin-relative form (SPEC.md section 6)
+__device__ __forceinline__ float z_at(const RecA& a, int32_t px, int32_t py) {
+    const long long A2 = (long long)(a.X2 - a.X0) * (long long)(a.Y1 - a.Y0) - (long long)(a.X1 - a.X0) * (long long)(a.Y2 - a.Y0);
+    const float rcpA = 1.0f / (float)A2;
+    const long long Px = (long long)px * 256 + 128, Py = (long long)py * 256 + 128;
+    const long long E1 = (long long)(a.Y0 - a.Y2) * (Px - a.X2) - (long long)(a.X0 - a.X2) * (Py - a.Y2);
+    const long long E2 = (long long)(a.Y1 - a.Y0) * (Px - a.X0) - (long long)(a.X1 - a.X0) * (Py - a.Y0);
+    const float b1 = (float)E1 * rcpA, b2 = (float)E2 * rcpA;
+    return fmaf(b2, a.z2 - a.z0, fmaf(b1, a.z1 - a.z0, a.z0));
 }
 
 // waves per bin: the passes (64 triangles each) of a bin are dealt round-robin to the waves of its workgroup;
@@ -145,12 +188,15 @@ __device__ __forceinline__ uint32_t shade_textured(const RecA& a, const RecB& b,
 // VIS_WAVES: 2 for unsharded frames (see above); a sharded rank has few bins and the frame then takes as long as its
 // heaviest bin (629 triangles = 183 batches of 64 pairs on the headline scene: 23 us with two waves), so the host
 // gives such frames 4 or 8 waves per bin (mtr_launch_tile_vis).
-template <bool TEX, int VIS_WAVES>
+template <bool TEX, int VIS_WAVES, bool STAIR>
 __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams P) {
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
     __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
     __shared__ unsigned long long s_start[VIS_WAVES][64];     // per batch of 64 pairs: which pairs start a triangle
     __shared__ uint32_t s_trans;                               // mixed frames: the queue holds an order-dependent triangle
+    __shared__ uint32_t s_hard;                                // ... one that prefix minima of z do not resolve: the ordered kernel's bin
+    __shared__ uint32_t s_cnt[STAIR ? MTR_BIN * MTR_BIN : 1];                      // STAIR: orders listed per pixel
+    __shared__ __align__(16) uint32_t s_list[STAIR ? MTR_BIN * MTR_BIN * STAIR_K : 4];  // STAIR: the orders (+ 1)
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -195,8 +241,11 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         if (P.fb.direct && threadIdx.x == 0 && !ovf) P.fb.bin_count[bin] = 0ull;
         return;
     }
-    for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) s_key[i] = 0ull;
-    if (threadIdx.x == 0) s_trans = 0u;
+    for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) {
+        s_key[i] = 0ull;
+        if (STAIR) s_cnt[i] = 0u;
+    }
+    if (threadIdx.x == 0) { s_trans = 0u; s_hard = 0u; }
     __syncthreads();
 
     const RecA zero_rec = {0, 0, 0, 0, 0, 0, 0.0f, 0.0f, 0.0f, 0u, 0u, 0u};
@@ -220,7 +269,10 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         uint32_t ord_nn = 0;
         if (e0 + 2 * stride + lane < N) ord_nn = P.fb.entries[ent_lo + e0 + 2 * stride + lane];
 
-        if (P.mixed && valid && (a_cur.pad1 >> 16)) s_trans = 1u;  // benign race: every writer stores 1
+        if (P.mixed && valid && (a_cur.pad1 >> 16)) {  // benign races: every writer stores 1
+            s_trans = 1u;
+            if (!STAIR || (a_cur.pad1 >> 17)) s_hard = 1u;
+        }
         Setup s = {};
         if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);
         const bool large = (s.t.flags & 1u) != 0;
@@ -253,7 +305,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                 const float e2f = (float)(eb2 + (long long)((flags >> 6) & 1u));
                 const float b1 = e1f * rcpA, b2 = e2f * rcpA;
                 const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
-                if (inside && z >= 0.0f && z <= 1.0f && z <= cd) atomicMax(&s_key[ly * MTR_BIN + lx], make_key(z, tord));
+                if (inside && z >= 0.0f && z <= 1.0f && z <= cd) put_fragment<STAIR>(s_key, s_cnt, s_list, (uint32_t)(ly * MTR_BIN + lx), make_key(z, tord));
             }
         }
 
@@ -313,7 +365,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                     // 0 <= z <= min(1, clear depth) as ONE unsigned compare of the bit patterns (z is never -0, SPEC.md;
                     // negative and NaN patterns are above every non-negative bound)
                     if ((eb0 | eb1 | eb2) >= 0 && __float_as_uint(z) <= zlim)
-                        atomicMax(&s_key[(box & 0xffu) + (uint32_t)(row * MTR_BIN + col)], make_key(z, q3.z));
+                        put_fragment<STAIR>(s_key, s_cnt, s_list, (box & 0xffu) + (uint32_t)(row * MTR_BIN + col), make_key(z, q3.z));
                 }
             }
         }
@@ -322,10 +374,17 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         ord_nxt = ord_nn;
     }
     __syncthreads();
-    if (P.mixed) {  // an order-dependent triangle in the queue: leave the bin (and its queue) to the ordered kernel
-        const bool tr = s_trans != 0u;
-        if (threadIdx.x == 0) P.bin_flag[bin] = tr ? 1 : 0;
-        if (tr) return;
+    bool stair = false;  // this bin resolves through its per-pixel order lists
+    if (P.mixed) {  // an order-dependent triangle in the queue
+        bool leave = s_hard != 0u;  // leave the bin (and its queue) to the ordered kernel
+        if (STAIR && !leave && s_trans) {
+            bool over = false;
+            for (uint32_t i = threadIdx.x; i < MTR_BIN * MTR_BIN; i += 64 * VIS_WAVES) over = over || s_cnt[i] > STAIR_K;
+            leave = __syncthreads_or(over ? 1 : 0) != 0;  // a pixel listed more orders than it has room for
+            stair = !leave;
+        }
+        if (threadIdx.x == 0) P.bin_flag[bin] = leave ? 1 : 0;
+        if (leave) return;
     }
     if (threadIdx.x == 0) {
         if (P.fb.direct && N) {  // queue statistics (direct mode has no scan to count them)
@@ -344,7 +403,42 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         const unsigned long long key = s_key[ly * MTR_BIN + lx];
         uint32_t col = P.clear_rgba8;
         float dep = cd;
-        if (key != 0ull) {
+        if (STAIR && stair) {
+            // the pixel's listed fragments in submission order; those that pass the depth test (z <= every earlier one's:
+            // running minimum, starting from the clear depth) are shaded and blended, exactly as the ordered kernel does
+            const uint32_t pix = (uint32_t)(ly * MTR_BIN + lx);
+            const uint32_t n = s_cnt[pix];
+            const uint4 l0 = reinterpret_cast<const uint4*>(&s_list[pix * STAIR_K])[0], l1 = reinterpret_cast<const uint4*>(&s_list[pix * STAIR_K])[1];
+            const uint32_t lst[STAIR_K] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            uint32_t last = 0;  // orders are stored + 1
+            for (;;) {
+                uint32_t best = 0xFFFFFFFFu;  // the smallest listed order above `last`
+#pragma unroll
+                for (uint32_t j = 0; j < STAIR_K; j++)
+                    if (j < n && lst[j] > last && lst[j] < best) best = lst[j];
+                if (best == 0xFFFFFFFFu) break;
+                last = best;
+                const uint32_t ord = best - 1u;
+                const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
+                const RecA a = load_rec(P.fb, r);
+                const float z = z_at(a, (int32_t)x, (int32_t)y);
+                if (!(z <= dep)) continue;  // fails LessEqual against the nearest of its predecessors
+                dep = z;
+                if (a.pad1 & 1u) {  // solid: its colour replaces the pixel
+                    col = a.pad0;
+                } else {
+                    const DMat mat = P.mats[a.mat];
+                    if (TEX && mat.shader == MTR_SH_TEXTURED) {
+                        const RecB b = P.fb.rec_b[r];
+                        float src[4];
+                        sample_textured(a, b, mat, (int32_t)x, (int32_t)y, src);
+                        col = blend_store(col, src, mat.blend == MTR_DB_ALPHA ? 1u : 0u);
+                    } else {
+                        col = mat.rgba8;
+                    }
+                }
+            }
+        } else if (key != 0ull) {
             dep = __uint_as_float(~(uint32_t)(key >> 32));
             const uint32_t ord = (uint32_t)key - 1u;
             const uint32_t r = (ord >> 7) * MTR_CHUNK_SLOTS + (ord & 127u);
@@ -380,8 +474,11 @@ void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
     if (p.vis_waves) waves = (int)p.vis_waves;
     else if (mine <= 1536) waves = 8;   // 256 CUs: every bin is resident at once, the heaviest bin bounds the frame
     else if (mine <= 4096) waves = 4;
-#define MTR_LAUNCH_VIS(T, W) hipLaunchKernelGGL((mtr::k_tile_vis<T, W>), dim3(grid), dim3(64 * W), 0, s, p)
-    if (textured) { if (waves >= 8) MTR_LAUNCH_VIS(true, 8); else if (waves >= 4) MTR_LAUNCH_VIS(true, 4); else MTR_LAUNCH_VIS(true, 2); }
-    else { if (waves >= 8) MTR_LAUNCH_VIS(false, 8); else if (waves >= 4) MTR_LAUNCH_VIS(false, 4); else MTR_LAUNCH_VIS(false, 2); }
+#define MTR_LAUNCH_VIS(T, W, S) hipLaunchKernelGGL((mtr::k_tile_vis<T, W, S>), dim3(grid), dim3(64 * W), 0, s, p)
+#define MTR_LAUNCH_VIS_W(T, S) do { if (waves >= 8) MTR_LAUNCH_VIS(T, 8, S); else if (waves >= 4) MTR_LAUNCH_VIS(T, 4, S); else MTR_LAUNCH_VIS(T, 2, S); } while (0)
+    // frames with translucent materials keep per-pixel order lists (STAIR); all-opaque frames need only the key
+    if (p.mixed) { if (textured) MTR_LAUNCH_VIS_W(true, true); else MTR_LAUNCH_VIS_W(false, true); }
+    else { if (textured) MTR_LAUNCH_VIS_W(true, false); else MTR_LAUNCH_VIS_W(false, false); }
+#undef MTR_LAUNCH_VIS_W
 #undef MTR_LAUNCH_VIS
 }

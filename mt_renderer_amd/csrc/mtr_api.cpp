@@ -1807,9 +1807,12 @@ static int32_t run_frame(mtr_frame* f) {
     for (const DMat& dm : mats) any_textured = any_textured || dm.shader == MTR_SH_TEXTURED;
     // some material translucent, some not: the visibility kernel takes the bins whose queue holds only opaque
     // triangles (order-free), flags the others, and the ordered kernel renders those in submission order
-    bool any_opaque = false;
-    for (const DMat& dm : mats) any_opaque = any_opaque || !dm.translucent;
-    const bool mixed = !use_vis && d->tile_mode == MTR_TILE_AUTO && any_opaque;
+    // ... and also the bins whose translucent triangles are merely alpha-blended in the default depth state (prefix minima
+    // of z, k_tile_vis.hip: STAIR).  Only when every material is HARD order-dependent (additive blend, depth write / test
+    // off) is there nothing for it to do.
+    bool any_soft = false;
+    for (const DMat& dm : mats) any_soft = any_soft || !dm.translucent || !(dm.blend == MTR_DB_ADD || dm.dstate != 3u);
+    const bool mixed = !use_vis && d->tile_mode == MTR_TILE_AUTO && any_soft;
     tp.bin_flag = sl.bin_flag; tp.mixed = mixed ? 1u : 0u;
     tp.zero_next = f->fb.other();
     f->fb.next_zeroed = fb.own.own_count != 0;  // a rank without a bin launches no tile workgroup

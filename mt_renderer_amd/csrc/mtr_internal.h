@@ -87,7 +87,8 @@ struct RecA {            // what coverage + depth need, in registers (see RecP f
     float z0, z1;
     float z2;
     uint32_t mat;
-    uint32_t pad0, pad1;  // pad0 = the colour of a solid triangle, pad1 = solid | blending << 8 | order-dependent << 16
+    uint32_t pad0, pad1;  // pad0 = the colour of a solid triangle, pad1 = solid | blending << 8 | order-dependent << 16 |
+                          // hard << 17 (order-dependent beyond what prefix minima of z resolve: additive blend, depth write / test off)
 };
 // RecA as it lives in HBM: 32 B.  A surviving triangle is written once by k_geom and read once per bin it touches by
 // the tile kernel (692 k reads per headline frame), so the record is what both kernels' traffic is made of.
@@ -96,7 +97,7 @@ struct RecA {            // what coverage + depth need, in registers (see RecP f
 //   q1 = { z0, z1, z2, payload }
 //   payload: top byte 0xFF = the quantised source colour of a debug-id / overlay triangle in the default depth state
 //            (their alpha is 1: whatever the blend, the fragment replaces the pixel); otherwise a triangle whose
-//            shading needs its material: material id (24 bits) | blend != off << 24 | order-dependent << 25
+//            shading needs its material: material id (24 bits) | blend != off << 24 | order-dependent << 25 | hard << 26
 struct RecP {
     uint4 q0, q1;
 };
@@ -109,8 +110,8 @@ __device__ __forceinline__ bool rec_is_large(const RecA& a) {
 }
 __device__ __forceinline__ RecP rec_pack(const RecA& a, bool large) {
     RecP p;
-    const uint32_t solid = a.pad1 & 1u, blend = (a.pad1 >> 8) & 1u, transl = (a.pad1 >> 16) & 1u;
-    const uint32_t payload = solid ? (a.pad0 | 0xFF000000u) : ((a.mat & 0xFFFFFFu) | (blend << 24) | (transl << 25));
+    const uint32_t solid = a.pad1 & 1u, blend = (a.pad1 >> 8) & 1u, transl = (a.pad1 >> 16) & 1u, hard = (a.pad1 >> 17) & 1u;
+    const uint32_t payload = solid ? (a.pad0 | 0xFF000000u) : ((a.mat & 0xFFFFFFu) | (blend << 24) | (transl << 25) | (hard << 26));
     const uint32_t d1 = large ? MTR_REC_LARGE_SENTINEL : (((uint32_t)(a.X1 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y1 - a.Y0) << 16));
     const uint32_t d2 = large ? 0u : (((uint32_t)(a.X2 - a.X0) & 0xFFFFu) | ((uint32_t)(a.Y2 - a.Y0) << 16));
     p.q0 = make_uint4((uint32_t)a.X0, (uint32_t)a.Y0, d1, d2);
@@ -129,9 +130,9 @@ __device__ __forceinline__ RecA rec_unpack(const RecP& p, const int4& l) {
     }
     a.z0 = __uint_as_float(p.q1.x); a.z1 = __uint_as_float(p.q1.y); a.z2 = __uint_as_float(p.q1.z);
     const uint32_t pl = p.q1.w;
-    // pad1: bit0 solid (pad0 is the colour, no material needed), bit8 blending on, bit16 order-dependent
+    // pad1: bit0 solid (pad0 is the colour, no material needed), bit8 blending on, bit16 order-dependent, bit17 hard
     if ((pl >> 24) == 0xFFu) { a.mat = 0; a.pad0 = pl; a.pad1 = 1u; }
-    else { a.mat = pl & 0xFFFFFFu; a.pad0 = 0; a.pad1 = (((pl >> 24) & 1u) << 8) | (((pl >> 25) & 1u) << 16); }
+    else { a.mat = pl & 0xFFFFFFu; a.pad0 = 0; a.pad1 = (((pl >> 24) & 1u) << 8) | (((pl >> 25) & 1u) << 16) | (((pl >> 26) & 1u) << 17); }
     return a;
 }
 
@@ -309,8 +310,9 @@ struct TileParams {
     float* depth;
     uint32_t clear_rgba8;
     float clear_depth;
-    // mixed frames (some material translucent): k_tile_vis renders the bins whose queue holds only opaque triangles and
-    // flags the others in bin_flag[]; k_tile then renders the flagged bins in submission order
+    // mixed frames (some material translucent): k_tile_vis renders the bins it can -- every triangle opaque, or translucent
+    // only through alpha blending in the default depth state (prefix minima of z, k_tile_vis.hip) -- and flags the others
+    // in bin_flag[]; k_tile then renders the flagged bins in submission order
     uint8_t* bin_flag;
     uint32_t mixed;
     // the counter block the NEXT frame on these framebuffers will use (CTR_NUM words), zeroed by this frame's tile

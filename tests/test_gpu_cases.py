@@ -343,13 +343,15 @@ def test_random_clip_space_soup(gpu_device, seed):
 
 
 def test_tile_kernel_selection(gpu_device):
-    """AUTO picks the visibility-key kernel exactly when every material is opaque."""
+    """AUTO picks the visibility-key kernel alone exactly when every material is opaque; a frame with alpha-blended
+    translucent materials goes through its order-list variant first (TILE_MIXED: the ordered kernel then takes the bins
+    that variant flags -- none here)."""
     from mt_renderer_amd import api
     w, h = 96, 64
     opaque = scene.random_bc7_texture(32, 32, 5, opaque_modes_only=True)
     translucent = scene.checker_rgba8_texture(8, 8, 1, alpha=(255, 254))
     q = [_quad(4, 4, 60, 60, .5, tex=0)]
-    for texs, want in (([opaque], api.TILE_VISIBILITY), ([translucent], api.TILE_ORDERED)):
+    for texs, want in (([opaque], api.TILE_VISIBILITY), ([translucent], api.TILE_MIXED)):
         md = pixel_model(q, texs)
         g = render_gpu(gpu_device, w, h, [dict(md=md, M=pixel_to_ndc_matrix(w, h))], tile_mode=api.TILE_AUTO)
         assert g[2]["tile_kernel"] == want
@@ -616,3 +618,54 @@ def test_fragment_lists_small_translucent_triangles_odd_viewport(gpu_device):
     g = render_gpu(gpu_device, w, h, draws)
     assert g[2]["tile_kernel"] in (api.TILE_ORDERED, api.TILE_MIXED) and g[2]["tris_setup"] > 2000, g[2]
     assert_same(g, render_oracle(w, h, draws), "fragment lists")
+
+
+def test_translucent_layers_resolve_through_prefix_minima(gpu_device):
+    """Alpha-blended translucent fragments in the default depth state: a pixel's result depends on submission order only
+    through the fragments that pass LessEqual, i.e. the prefix minima of z -- what the visibility kernel's order lists hold
+    (k_tile_vis.hip, STAIR).  Layered quads over the same pixels: depths falling in submission order (every layer passes
+    and blends), rising (only the first passes), shuffled, exact ties (a later equal z passes too), an opaque layer in
+    the middle (replaces what is below), more passing layers than a list holds (the bin falls back to the ordered
+    kernel), and a hard order-dependent material next to them (additive blend: its bins are the ordered kernel's).
+    AUTO == ORDERED == oracle, bit for bit (render through _px: every queue builder x both tile paths)."""
+    from mt_renderer_amd import api
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(16, 16, 4), dtype=np.uint8)
+    img[..., 3] = rng.integers(30, 230, size=(16, 16))
+    translucent = scene.TextureData(16, 16, scene.TEX_RGBA8, img.tobytes())
+    opaque = scene.random_bc7_texture(16, 16, 9, opaque_modes_only=True)
+
+    def layers(zs, x0=3.0, y0=2.0, size=26.0, step=0.7, texs=None):
+        out = []
+        for i, z in enumerate(zs):
+            t = 0 if texs is None else texs[i]
+            out.append(_quad(x0 + step * i, y0 + 0.4 * i, x0 + step * i + size, y0 + 0.4 * i + size, z, tex=t, did=i,
+                             u0=0.1 * (i % 3), v0=0.07 * (i % 4), u1=1.0 + 0.2 * (i % 2), v1=0.9))
+        return out
+
+    falling = [0.9 - 0.05 * i for i in range(7)]
+    shuffled = [float(v) for v in rng.permutation(np.linspace(0.2, 0.8, 8))]
+    cases = {
+        "falling": layers(falling),
+        "rising": layers(falling[::-1]),
+        "shuffled": layers(shuffled),
+        "ties": layers([0.5, 0.5, 0.6, 0.5, 0.4, 0.4, 0.7]),
+        "opaque in the middle": layers([0.8, 0.7, 0.6, 0.5, 0.4], texs=[0, 0, 1, 0, 0]) + [dict(verts=[(8, 8, .45), (8, 30, .45), (30, 30, .45)], indices=[0, 1, 2], debug_id=4)],
+        "twelve passing layers": layers([0.95 - 0.05 * i for i in range(12)], step=0.3),
+        "two bins, one deep": layers(shuffled, x0=2.0) + layers([0.95 - 0.04 * i for i in range(11)], x0=40.0, step=0.2),
+    }
+    for name, prims in cases.items():
+        g = _px(gpu_device, prims, w=80, h=48, textures=[translucent, opaque])
+        assert g[2]["tile_kernel"] == api.TILE_MIXED, (name, g[2])
+    # a hard order-dependent material (additive blend) among alpha-blended ones: per primitive state
+    prims = layers(shuffled[:5]) + layers([0.3, 0.6, 0.2], x0=44.0)
+    md = pixel_model(prims, [translucent, opaque])
+    st = np.tile(np.array([[api_blend("alpha"), 1, 1, 0]], dtype=np.uint8), (md.nprims, 1))
+    st[6, 0] = api_blend("add")
+    md.prim_states = st
+    M = pixel_to_ndc_matrix(80, 48)
+    _both(gpu_device, 80, 48, [dict(md=md, M=M)])
+
+
+def api_blend(name):
+    return {"alpha": 0, "off": 1, "add": 2}[name]  # include/mtr.h: MTR_BLEND_*
