@@ -519,8 +519,11 @@ def main():
     alg_frame, alg_geom, alg_tile = algorithmic_bytes(md, W, H, 1)
     direct = stats["binning"] == 1
     vis = stats["tile_kernel"] == 2
-    names = {"geom": "k_geom<%d, %s>" % (((2 if vis else 1) if direct else 0), "true" if sharded and own[0] != api.OWN_INTERLEAVED else "false"),
-             "scan": "k_scan", "fill": "k_fill", "tile": ("k_tile_vis<false, %d>" % (2 if stats["shard_bins"] > 4096 else (4 if stats["shard_bins"] > 1536 else 8))) if vis else "k_tile<false>"}
+    # kernel names as rocprofv3 prints them: k_geom<queue builder, culled launch, waves per SIMD it is built for (7: a draw of
+    # fewer than 65536 geometry waves)>, k_tile_vis<textured, waves per bin, order lists>
+    names = {"geom": "k_geom<%d, %s, %d>" % (((2 if vis else 1) if direct else 0), "true" if sharded and own[0] != api.OWN_INTERLEAVED else "false",
+                                             7 if stats["chunks"] < 65536 else 8),
+             "scan": "k_scan", "fill": "k_fill", "tile": ("k_tile_vis<false, %d, false>" % (2 if stats["shard_bins"] > 4096 else (4 if stats["shard_bins"] > 1536 else 8))) if vis else "k_tile<false>"}
     alg = {"geom": alg_geom, "tile": alg_tile}
     traffic_by_kernel = pmc_traffic() if world == 1 else {}
     kernels = {}

@@ -434,16 +434,21 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 }
 
 #ifndef GEOM_OCC
-#define GEOM_OCC 6  // waves per SIMD the register allocator must leave room for (80 VGPRs + 144 B of scratch in the
-                    // rare clip path; with three frames in flight 6 beats 4 by 7 % per frame, tools/sweep_overlap.sh)
+#define GEOM_OCC 8  // waves per SIMD the register allocator must leave room for: 64 VGPRs.  Rounds 1-2 ran at 6 (80 VGPRs,
+                    // the vertex stage's live ranges spilled below that); with the vertex stage feeding LDS the kernel fits 64
+                    // without spills and the instanced configs gain 8-10 % (C5 0.903 -> 0.813 ms; tools/sweep_geom_occ.sh)
+#define GEOM_OCC_SMALL 7  // a draw that does not fill the GPU (the headline model: 16 k waves) overlaps with the neighbouring
+                    // frames' tile kernels for most of its life and does better leaving them a wave slot per SIMD, with the
+                    // 72 registers that allows: 0.0485 ms per frame against 0.0509 at 8 and 0.0498 at 6 (three runs each,
+                    // tools/probe/occ_repeat.sh); capping the residency of the 64-register build by LDS gets 0.0498
 #endif
 // 256 threads, wave = one chunk (62 strip positions) of one instance.  Unsharded frames (CULL false): grid = (blocks
 // of 4 chunks, instances).  Sharded frames (CULL true): k_cull_chunks has bounded every chunk against the rank's bins
 // and written the survivors to a work list; the workgroups stride over it.  (Testing the bounds inside this kernel --
 // 80 registers, 6 workgroups per CU -- put the test's chain of dependent loads on every workgroup's critical path:
 // +11 us on the headline scene even when nothing was culled.)
-template <int MODE, bool CULL>
-__global__ __launch_bounds__(256, GEOM_OCC) void k_geom(GeomParams P) {
+template <int MODE, bool CULL, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_geom(GeomParams P) {
     extern __shared__ __align__(16) float s_pal[];
     __shared__ RecHdr s_hdr[4][MTR_CHUNK_SLOTS + 4];
     __shared__ uint32_t s_slot[MODE == 2 ? 4 : 1][128];  // unordered binning: per-wave bin-window counters / offsets
@@ -688,6 +693,14 @@ __global__ __launch_bounds__(256) void k_vertex_stage(GeomParams P, uint32_t pri
 
 }  // namespace mtr
 
+// MODE by the frame's queue builder, the register budget by the size of the draw
+#define MTR_LAUNCH_GEOM_O(C, O)                                                                                         \
+    do {                                                                                                                \
+        if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, C, O>), grid, dim3(256), lds, s, p);      \
+        else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, C, O>), grid, dim3(256), lds, s, p);                   \
+        else hipLaunchKernelGGL((mtr::k_geom<0, C, O>), grid, dim3(256), lds, s, p);                                    \
+    } while (0)
+#define MTR_LAUNCH_GEOM(C) do { if (p.small_draw) MTR_LAUNCH_GEOM_O(C, GEOM_OCC_SMALL); else MTR_LAUNCH_GEOM_O(C, GEOM_OCC); } while (0)
 void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     if (p.nchunks == 0 || p.ninst == 0) return;
     size_t lds = (size_t)p.npal * 64;
@@ -705,9 +718,7 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
         if ((uint64_t)(p.ninst - slots) * p.work_nx * 4u <= 20000u) slots = p.ninst;
         if (p.slots_override) slots = std::min<uint32_t>(p.ninst, p.slots_override);  // MTR_GEOM_SLOTS at device creation: tests force the second launch
         dim3 grid(p.work_nx * 4u * slots);  // the host checked work_nx * 4 * ninst against the launch limit (2^32 threads)
-        if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, true>), grid, dim3(256), lds, s, p);
-        else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((mtr::k_geom<0, true>), grid, dim3(256), lds, s, p);
+        MTR_LAUNCH_GEOM(true);
         if (slots < p.ninst) {
             GeomParams r = p;
             r.work_slot_base = slots;
@@ -721,9 +732,7 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
     uint32_t nblk = (p.nchunks + 3) / 4;
     nblk = (nblk + 7) / 8 * 8;  // whole multiple of 8 for the XCD remap
     dim3 grid(nblk, p.ninst);
-    if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom<2, false>), grid, dim3(256), lds, s, p);
-    else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom<1, false>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((mtr::k_geom<0, false>), grid, dim3(256), lds, s, p);
+    MTR_LAUNCH_GEOM(false);
 }
 
 void mtr_launch_cull_instances(const CullParams& p, hipStream_t s) {

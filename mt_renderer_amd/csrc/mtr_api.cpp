@@ -149,6 +149,7 @@ struct mtr_device {
     // slots the full-rate sharded geometry launch covers (tests force k_geom_rest with it); 0xFFFFFFFF / 0: not set
     uint32_t cull_debug = 0xFFFFFFFFu;
     uint32_t geom_slots = 0;
+
     // Tile-kernel bin order across the 8 XCDs.  One contiguous eighth of the bins per XCD keeps the records of
     // neighbouring bins in one L2 and gives the shortest stand-alone kernel (48.9 us), but the XCDs that own the empty top
     // and bottom of a frame run dry while the middle ones work; dealing runs of a quarter bin row to the XCDs in turn
@@ -1789,6 +1790,9 @@ static int32_t run_frame(mtr_frame* f) {
             gp.inst_list = cc.inst_list; gp.inst_count = cc.inst_count;
         }
         gp.slots_override = d->geom_slots;
+        // a draw of fewer than ~64 k geometry waves (the headline model: 16 k) overlaps with the neighbouring frames' tile
+        // kernels for most of its life: the build that leaves them a wave slot per SIMD (k_geom.hip: GEOM_OCC_SMALL)
+        gp.small_draw = ((uint64_t)gp.nchunks * dr.ninst < 65536u) ? 1u : 0u;
         mtr_launch_geom(gp, sg);
         HIPCHK(d, hipGetLastError());
         chunk_base += gp.nchunks * dr.ninst;

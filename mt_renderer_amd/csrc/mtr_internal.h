@@ -291,6 +291,7 @@ struct GeomParams {
     uint32_t work_nx;          // groups of 16 chunks per instance = ceil(nchunks / 16)
     uint32_t work_slot_base;   // k_geom_rest: the first instance slot of its launch
     uint32_t slots_override;   // 0, or the number of instance slots the full-rate launch covers (MTR_GEOM_SLOTS, tests)
+    uint32_t small_draw;       // the draw does not fill the GPU: the build of k_geom that leaves a wave slot per SIMD free
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instance slot ii is instance ii
     const uint32_t* inst_count;  // length of inst_list (device), or nullptr: ninst
     const float* model_mats;  // ninst*16 or nullptr
