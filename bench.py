@@ -333,27 +333,42 @@ def main():
                 dev.exchange_stop()
                 self.xthread = False
 
-    def sync(ex, what):
-        """every frame issued so far is complete on every rank, and no rank is in error: a rank whose exchange or whose
-        frames failed still took part in every collective (the library sends a clear-colour shard), reports here, and ALL
-        ranks leave together -- nobody is left waiting for a peer that has gone"""
-        err = None
+    pending_error = []  # what fence() caught: check() reports it (after the clock has been read)
+
+    def fence(ex):
+        """what brackets a timed region, and nothing else: every frame issued so far has been handed to the GPU and has left it,
+        on every rank (barrier + torch.cuda.synchronize(), as the driver's contract says)"""
         try:
             if ex is not None and ex.xthread:
                 dev.exchange_drain()  # every handed-over frame has been issued; raises the exchange thread's first error
+        except api.MtrError as e:
+            pending_error.append(e)
+        torch.cuda.synchronize()
+        if sharded:
+            dist.barrier()
             torch.cuda.synchronize()
+
+    def check(what):
+        """no rank is in error: a rank whose exchange or whose frames failed still took part in every collective (the library
+        sends a clear-colour shard), reports here, and ALL ranks leave together -- nobody is left waiting for a peer that has
+        gone.  Outside the timed regions: the agreement is a collective of its own."""
+        err = pending_error.pop() if pending_error else None
+        pending_error.clear()
+        try:
             dev.synchronize()  # raises if a frame nobody waited for overflowed its bin queues (it would be missing triangles)
         except api.MtrError as e:
-            err = e
+            err = err or e
         if sharded:
             if not all_ok(err is None):
                 print(f"[rank {rank}] {what}: {'FAILED: ' + str(err) if err else 'ok here, another rank failed'}; every rank exits", file=sys.stderr, flush=True)
                 watchdog.disarm()
                 sys.exit(4)
-            dist.barrier()
-            torch.cuda.synchronize()
         elif err is not None:
             raise err
+
+    def sync(ex, what):
+        fence(ex)
+        check(what)
 
     def run_frames(work, ex, loop, n, shard_args):
         """n frames, submitted back to back, nothing waited for"""
@@ -423,8 +438,9 @@ def main():
         for _ in range(reps):
             t0 = time.perf_counter()
             run_frames(work, ex, loop, steps, shard_args)
-            sync(ex, f"{work.name} timed region")
+            fence(ex)  # barrier + synchronize: the end of the timed region
             dts.append(time.perf_counter() - t0)
+            check(f"{work.name} timed region")
         watchdog.disarm()
         if sharded:
             t = torch.tensor(dts, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

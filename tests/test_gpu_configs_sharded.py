@@ -129,9 +129,9 @@ def test_c4_full_size_every_rank_bands_and_culling(gpu_device):
         scn.close()
 
 
-def _c5_scene(dev, nx, ny, tex_size=1024):
+def _c5_scene(dev, nx, ny, tex_size=1024, opaque=True):
     n = nx * ny
-    texs = [scene.random_bc7_texture(tex_size, tex_size, seed=200 + i, opaque_modes_only=True) for i in range(max(1, n // 16))]
+    texs = [scene.random_bc7_texture(tex_size, tex_size, seed=200 + i, opaque_modes_only=opaque) for i in range(max(1, n // 16))]
     md = scene.mesh50k(textured=True, textures=texs)
     return Resident(dev, md, nx, ny, tex_override=[i // 16 for i in range(n)])
 
@@ -187,10 +187,12 @@ def test_c5_full_size_remainder_kernel(monkeypatch):
         dev0.close()
 
 
-def test_c5_64_instances_vs_oracle_under_8_way_bands(gpu_device):
+@pytest.mark.parametrize("opaque", [True, False], ids=["opaque", "translucent"])
+def test_c5_64_instances_vs_oracle_under_8_way_bands(gpu_device, opaque):
     """C5 at the size the oracle renders in seconds (64 instances, 4 BC7 textures, 3840x2160): the frame assembled from
-    the own pixels of the 8 ranks (balanced bands, culling on) is the ORACLE's frame, bit for bit."""
-    scn = _c5_scene(gpu_device, 8, 8, tex_size=256)
+    the own pixels of the 8 ranks (balanced bands, culling on) is the ORACLE's frame, bit for bit.  Translucent set: the
+    ranks resolve alpha blending through the visibility kernel's order lists (flagged bins: the ordered kernel)."""
+    scn = _c5_scene(gpu_device, 8, 8, tex_size=256, opaque=opaque)
     try:
         draws = [dict(md=scn.md, vp=scn.vp, model_mats=scn.mats, palettes=scn.pals, tex_override=scn.tex_override)]
         oc, od, ost = render_oracle(W4K, H4K, draws, nthreads=16)
