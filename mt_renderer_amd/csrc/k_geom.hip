@@ -440,7 +440,7 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 #define GEOM_OCC_SMALL 7  // a draw that does not fill the GPU (the headline model: 16 k waves) overlaps with the neighbouring
                     // frames' tile kernels for most of its life and does better leaving them a wave slot per SIMD, with the
                     // 72 registers that allows: 0.0485 ms per frame against 0.0509 at 8 and 0.0498 at 6 (three runs each,
-                    // tools/probe/occ_repeat.sh); capping the residency of the 64-register build by LDS gets 0.0498
+                    // tools/sweep_geom_occ.sh); capping the residency of the 64-register build by LDS gets 0.0498
 #endif
 // 256 threads, wave = one chunk (62 strip positions) of one instance.  Unsharded frames (CULL false): grid = (blocks
 // of 4 chunks, instances).  Sharded frames (CULL true): k_cull_chunks has bounded every chunk against the rank's bins
