@@ -142,12 +142,22 @@ __device__ __forceinline__ void stage_palette(const GeomParams& P, uint32_t inst
     __syncthreads();
 }
 
+// the strip position shading lane `lane` takes (rail order for strips, identity for lists; geom_chunk)
+__device__ __forceinline__ uint32_t shading_position(const DPrim& pr, uint32_t lane) {
+    return pr.topology == 4 ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
+}
+// index fetch (Uint16, src/model.rs:307) for that position; 0xFFFF outside the primitive's index range
+__device__ __forceinline__ uint32_t fetch_index(const GeomParams& P, const DChunk& ch, const DPrim& pr, uint32_t lane) {
+    const int32_t ps = (int32_t)ch.start - 2 + (int32_t)shading_position(pr, lane);
+    return (ps >= 0 && (uint32_t)ps < pr.index_num) ? (uint32_t)P.ibuf[pr.index_ofs + (uint32_t)ps] : 0xFFFFu;
+}
+
 // MODE 0: count pass of the exact two-pass queues; 1: single-pass binning, ordered segments; 2: single-pass binning
 // for frames the visibility-key tile kernel renders (no order kept, no segments)
 template <int MODE>
 __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, uint32_t c, const DChunk& ch, const DPrim& pr,
                                            bool skinned, const float* s_M, const float* s_pal, RecHdr* s_hdr, uint32_t* s_slot,
-                                           float4* s_pv, uint32_t lane) {
+                                           float4* s_pv, uint32_t lane, uint32_t idx) {
     const uint32_t gid = P.chunk_base + inst * P.nchunks + c;
     const uint32_t mat = P.mat_base + inst * P.mat_inst_stride + ch.prim;
     const uint32_t W = P.fb.W, H = P.fb.H;
@@ -164,12 +174,12 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     //      ones; a block is four consecutive vertices of ONE rail.  The projected vertices go through 1-2 KB of LDS private
     //      to the wave (written at pi(s), read back at the lane's own position): no shuffle, no workgroup barrier.
     //      Triangle lists keep the identity order. ----
-    const uint32_t sp = strip ? (((lane & 31u) << 1) | (lane >> 5)) : lane;
+    const uint32_t sp = shading_position(pr, lane);
     {
-        // index fetch (Uint16, src/model.rs:307)
+        // `idx`: the index at this lane's shading position (fetch_index: the caller issues the load before the palette
+        // barrier, so its round trip overlaps with the staging instead of following it)
         const int32_t ps = (int32_t)ch.start - 2 + (int32_t)sp;
         const bool in_s = ps >= 0 && (uint32_t)ps < pr.index_num;
-        const uint32_t idx = in_s ? (uint32_t)P.ibuf[pr.index_ofs + (uint32_t)ps] : 0xFFFFu;
         const bool restart_s = !in_s || (strip && idx == 0xFFFFu);
         const uint32_t vid_s = idx + pr.index_base;  // base_vertex = index_base, src/model.rs:359
         const bool valid_s = !restart_s && vid_s < pr.vertex_num;
@@ -464,11 +474,16 @@ __global__ __launch_bounds__(256, OCC) void k_geom(GeomParams P) {
         const uint32_t blk = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
         const uint32_t c = blk * 4 + wave;
         if (blk >= nblk) return;  // whole workgroup
+        // the chunk, its primitive and the wave's indices are requested BEFORE the palette is staged: three dependent round
+        // trips that used to follow the staging barrier now overlap with it
+        const bool has = c < P.nchunks;
+        DChunk ch = {};
+        DPrim pr = {};
+        uint32_t idx = 0xFFFFu;
+        if (has) { ch = P.chunks[c]; pr = P.prims[ch.prim]; idx = fetch_index(P, ch, pr, lane); }
         stage_palette(P, blockIdx.y, s_pal, s_M);  // every thread of the workgroup copies its share
-        if (c >= P.nchunks) return;
-        const DChunk ch = P.chunks[c];
-        const DPrim pr = P.prims[ch.prim];
-        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
+        if (!has) return;
+        geom_chunk<MODE>(P, blockIdx.y, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane, idx);
         return;
     }
     // sharded: workgroup g = (group x, quarter q) fastest, then instance slot ii: it takes the q-th four survivors of the 16
@@ -491,15 +506,18 @@ __global__ __launch_bounds__(256, OCC) void k_geom(GeomParams P) {
     const uint32_t m16 = (mi & 1u) ? mword >> 16 : mword & 0xFFFFu;
     const uint32_t k = (uint32_t)__popc(m16);
     if (q * 4u >= k) return;
-    stage_palette(P, inst, s_pal, s_M);
     const uint32_t nth = q * 4u + wave;  // this wave's survivor
-    if (nth >= k) return;
+    const bool has = nth < k;
     uint32_t mm = m16;
-    for (uint32_t t = 0; t < nth; t++) mm &= mm - 1u;  // drop the nth lowest set bits (wave-uniform)
-    const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
-    const DChunk ch = P.chunks[c];
-    const DPrim pr = P.prims[ch.prim];
-    geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
+    for (uint32_t t = 0; t < nth && mm; t++) mm &= mm - 1u;  // drop the nth lowest set bits (wave-uniform)
+    const uint32_t c = x * 16u + (mm ? (uint32_t)__ffs((int)mm) - 1u : 0u);
+    DChunk ch = {};
+    DPrim pr = {};
+    uint32_t idx = 0xFFFFu;
+    if (has) { ch = P.chunks[c]; pr = P.prims[ch.prim]; idx = fetch_index(P, ch, pr, lane); }  // before the barrier, as above
+    stage_palette(P, inst, s_pal, s_M);
+    if (!has) return;
+    geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane, idx);
 }
 
 // The instance slots the full-rate launch of k_geom<MODE, true> does not cover (mtr_launch_geom): MTR_GEOM_REST_SPLIT
@@ -532,7 +550,8 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
             const uint32_t c = x * 16u + (uint32_t)__ffs((int)mm) - 1u;
             const DChunk ch = P.chunks[c];
             const DPrim pr = P.prims[ch.prim];
-            geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane);
+            geom_chunk<MODE>(P, inst, c, ch, pr, pr.skinnable && P.palettes && P.npal, s_M, s_pal, s_hdr[wave], s_slot[wave], s_pv[wave], lane,
+                             fetch_index(P, ch, pr, lane));
         }
     }
 }

@@ -396,6 +396,8 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 
     // ---- resolve: deferred shading of each pixel's winner, the only framebuffer traffic of the frame;
     //      one pixel per thread, rows of 16 pixels = 64 contiguous bytes ----
+    // (unrolled: a thread's pixels are independent, so their winner-record loads are in flight together)
+#pragma unroll
     for (uint32_t pidx = threadIdx.x; pidx < MTR_BIN * MTR_BIN; pidx += 64 * VIS_WAVES) {
         const int32_t lx = (int32_t)(pidx & (MTR_BIN - 1)), ly = (int32_t)(pidx >> MTR_BIN_SHIFT);
         if (lx >= vw || ly >= vh) continue;
