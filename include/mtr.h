@@ -284,6 +284,35 @@ int32_t mtr_device_exchange_add_lane(mtr_device *dev, void *comm, void *send_dev
 int32_t mtr_frame_submit_exchange(mtr_frame *frame);
 int32_t mtr_device_exchange_drain(mtr_device *dev);
 int32_t mtr_device_exchange_stop(mtr_device *dev);
+/* ---- one host thread, N devices ("mtr_group_create(const int* devices, int n, mtr_group**) + same frame calls") ----
+ * The reference has one event loop and one wgpu::Device (src/renderer_app_manager.rs:202-272).  A host that keeps that shape
+ * and owns several GPUs of one node drives them through a group: rank r of the group is an mtr_device on hip_devices[r]
+ * (an index may repeat: several ranks on one card), a group frame is one sharded frame per rank under one ownership map
+ * (mtr_frame_set_shard_map's arguments), and ending it gathers the colour of every part into one linear RGBA8 image on
+ * the device of rank 0: pack on each device, one peer copy per rank (xGMI where the devices are peers), unpack.
+ *   resources are per device: create the model / textures / batches on mtr_group_device(group, r) for every r;
+ *   drawing is "the same frame calls": mtr_frame_draw_* into mtr_group_frame_part(gf, r) with rank r's objects
+ *       (the parts are owned by the group frame: never submit, wait for or destroy them yourself);
+ *   mtr_group_frame_end submits every part, waits for all of them (a part whose bin queues overflowed is re-run first)
+ *       and returns with the gathered image complete; it stays readable until the next group frame of the group ends;
+ *   mtr_group_destroy destroys the group's devices: destroy their models, textures, batches and group frames first.
+ * A group is driven by one thread and ends one frame at a time; the throughput path for N GPUs is one process (or host
+ * thread) per device with the exchange thread above.  Errors: mtr_group_last_error(group)
+ * (NULL: the last mtr_group_create failure). */
+typedef struct mtr_group mtr_group;
+typedef struct mtr_group_frame mtr_group_frame;
+int32_t mtr_group_create(const int32_t *hip_devices, int32_t n, mtr_group **out); /* 1 <= n <= 64 */
+void mtr_group_destroy(mtr_group *group);
+int32_t mtr_group_size(const mtr_group *group);
+mtr_device *mtr_group_device(mtr_group *group, int32_t rank);
+const char *mtr_group_last_error(const mtr_group *group);
+int32_t mtr_group_frame_begin(mtr_group *group, uint32_t width, uint32_t height, const float clear_rgba[4], float clear_depth,
+                              uint32_t map, uint32_t param, const uint32_t *band_rows, mtr_group_frame **out);
+mtr_frame *mtr_group_frame_part(mtr_group_frame *gframe, int32_t rank);
+int32_t mtr_group_frame_end(mtr_group_frame *gframe);
+int32_t mtr_group_frame_read_color(mtr_group_frame *gframe, void *rgba8, size_t len); /* width*height*4 */
+void *mtr_group_frame_color_devptr(mtr_group_frame *gframe); /* on rank 0's device; NULL once a later group frame has ended */
+void mtr_group_frame_destroy(mtr_group_frame *gframe);
 int32_t mtr_frame_get_stats(mtr_frame *frame, mtr_frame_stats *out);
 int32_t mtr_frame_get_timings(mtr_frame *frame, float ms[MTR_STAGE_COUNT]);
 /* tuning / test hook: per-bin queue sizes of the frame just rendered (valid until the next frame is submitted on

@@ -6,6 +6,7 @@
 #include "mtr.h"
 
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -24,9 +25,14 @@ class Device {
         int32_t rc = mtr_device_create(hip_device, &h_);
         if (rc) throw Error(rc, mtr_last_error(nullptr));
     }
+    // rank r of a Group: the group owns the device
+    struct Borrowed {};
+    Device(mtr_device* of_group, Borrowed) : h_(of_group), owned_(false) {}
     Device(const Device&) = delete;
     Device& operator=(const Device&) = delete;
-    ~Device() { mtr_device_destroy(h_); }
+    ~Device() {
+        if (owned_) mtr_device_destroy(h_);
+    }
     mtr_device* handle() const { return h_; }
     void set_tile_mode(int32_t mode) const { check(mtr_device_set_tile_mode(h_, mode)); }  // MTR_TILE_AUTO / ORDERED / VISIBILITY
     void set_binning(bool single_pass, uint32_t queue_capacity = 0) const { check(mtr_device_set_binning(h_, single_pass ? 1 : 0, queue_capacity)); }
@@ -53,6 +59,7 @@ class Device {
 
   private:
     mtr_device* h_ = nullptr;
+    bool owned_ = true;
 };
 
 class Texture {
@@ -118,8 +125,12 @@ class Frame {
     Frame(const Device& dev, uint32_t width, uint32_t height, const float clear_rgba[4], float clear_depth) : dev_(dev) {
         dev.check(mtr_frame_begin(dev.handle(), width, height, clear_rgba, clear_depth, &h_));
     }
+    // part r of a GroupFrame: the group frame owns (submits, waits for, destroys) it; draw into it, nothing else
+    Frame(const Device& dev, mtr_frame* part_of_group_frame) : dev_(dev), h_(part_of_group_frame), owned_(false) {}
     Frame(const Frame&) = delete;
-    ~Frame() { mtr_frame_destroy(h_); }
+    ~Frame() {
+        if (owned_) mtr_frame_destroy(h_);
+    }
     void end() { dev_.check(mtr_frame_end(h_)); }  // queue.submit, src/renderer_app_manager.rs:185
     // end() in two halves, so a host can keep several frames in flight (the library overlaps them on its own streams)
     void submit() { dev_.check(mtr_frame_submit(h_)); }
@@ -155,6 +166,7 @@ class Frame {
   private:
     const Device& dev_;
     mtr_frame* h_ = nullptr;
+    bool owned_ = true;
 };
 
 inline void Model::render(Frame& frame, const float view_proj[16]) const {
@@ -164,6 +176,56 @@ inline void Model::render(Frame& frame, const float view_proj[16]) const {
 inline void Model::render_with_joints(Frame& frame, const float view_proj[16]) const {
     dev_.check(mtr_frame_draw_model_joints(frame.handle(), h_, view_proj));
 }
+
+// One host thread, N devices (mtr.h: mtr_group_*).  device(r) creates rank r's models / textures; a GroupFrame is one sharded
+// Frame per rank -- draw into part(r) with rank r's objects -- and end() leaves the gathered RGBA8 image on rank 0's device.
+class Group {
+  public:
+    explicit Group(const std::vector<int32_t>& hip_devices) {
+        int32_t rc = mtr_group_create(hip_devices.data(), (int32_t)hip_devices.size(), &h_);
+        if (rc) throw Error(rc, mtr_group_last_error(nullptr));
+        for (int32_t r = 0; r < mtr_group_size(h_); r++) devs_.emplace_back(new Device(mtr_group_device(h_, r), Device::Borrowed{}));
+    }
+    Group(const Group&) = delete;
+    Group& operator=(const Group&) = delete;
+    ~Group() {
+        devs_.clear();
+        mtr_group_destroy(h_);
+    }
+    size_t size() const { return devs_.size(); }
+    const Device& device(size_t rank) const { return *devs_.at(rank); }
+    mtr_group* handle() const { return h_; }
+    void check(int32_t rc) const {
+        if (rc) throw Error(rc, mtr_group_last_error(h_));
+    }
+
+  private:
+    mtr_group* h_ = nullptr;
+    std::vector<std::unique_ptr<Device>> devs_;
+};
+
+class GroupFrame {
+  public:
+    GroupFrame(const Group& group, uint32_t width, uint32_t height, const float clear_rgba[4], float clear_depth,
+               uint32_t map = MTR_OWN_BANDS, uint32_t param = 0, const uint32_t* band_rows = nullptr) : group_(group) {
+        group.check(mtr_group_frame_begin(group.handle(), width, height, clear_rgba, clear_depth, map, param, band_rows, &h_));
+        for (size_t r = 0; r < group.size(); r++) parts_.emplace_back(new Frame(group.device(r), mtr_group_frame_part(h_, (int32_t)r)));
+    }
+    GroupFrame(const GroupFrame&) = delete;
+    ~GroupFrame() {
+        parts_.clear();
+        mtr_group_frame_destroy(h_);
+    }
+    Frame& part(size_t rank) { return *parts_.at(rank); }
+    void end() { group_.check(mtr_group_frame_end(h_)); }
+    void read_color(void* rgba8, size_t len) { group_.check(mtr_group_frame_read_color(h_, rgba8, len)); }
+    void* color_devptr() const { return mtr_group_frame_color_devptr(h_); }
+
+  private:
+    const Group& group_;
+    mtr_group_frame* h_ = nullptr;
+    std::vector<std::unique_ptr<Frame>> parts_;
+};
 
 // The reference's app seam (src/renderer_app_manager.rs:14-32), headless: the "frame_view + encoder" pair is the Frame.
 struct RendererApp {

@@ -40,6 +40,8 @@ EXPORTED_SYMBOLS = [
     "mtr_frame_pack_color_shard_on_stream", "mtr_device_unpack_color_shards_on_stream",
     "mtr_device_synchronize", "mtr_model_set_joint_positions", "mtr_frame_draw_model_joints", "mtr_model_set_prim_states", "mtr_texture_create_mips", "mtr_frame_set_shard_map", "mtr_device_set_culling", "mtr_device_set_texture_residency", "mtr_shard_bytes_map", "mtr_frame_shard_bytes",
     "mtr_frame_unpack_color_shards_on_stream", "mtr_device_exchange_start", "mtr_device_exchange_add_lane", "mtr_frame_submit_exchange", "mtr_device_exchange_drain", "mtr_device_exchange_stop",
+    "mtr_group_create", "mtr_group_destroy", "mtr_group_size", "mtr_group_device", "mtr_group_last_error", "mtr_group_frame_begin",
+    "mtr_group_frame_part", "mtr_group_frame_end", "mtr_group_frame_read_color", "mtr_group_frame_color_devptr", "mtr_group_frame_destroy",
 ]
 
 
@@ -145,6 +147,17 @@ def _load() -> C.CDLL:
         "mtr_frame_read_bin_counts": (i32, [vp, vp, vp, sz]),
         "mtr_device_set_tile_mode": (i32, [vp, i32]),
         "mtr_device_set_binning": (i32, [vp, i32, u32]),
+        "mtr_group_create": (i32, [vp, i32, C.POINTER(vp)]),
+        "mtr_group_destroy": (None, [vp]),
+        "mtr_group_size": (i32, [vp]),
+        "mtr_group_device": (vp, [vp, i32]),
+        "mtr_group_last_error": (C.c_char_p, [vp]),
+        "mtr_group_frame_begin": (i32, [vp, u32, u32, vp, C.c_float, u32, u32, vp, C.POINTER(vp)]),
+        "mtr_group_frame_part": (vp, [vp, i32]),
+        "mtr_group_frame_end": (i32, [vp]),
+        "mtr_group_frame_read_color": (i32, [vp, vp, sz]),
+        "mtr_group_frame_color_devptr": (vp, [vp]),
+        "mtr_group_frame_destroy": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -246,7 +259,8 @@ class Device:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.mtr_device_destroy(self._h)
+            if not getattr(self, "_borrowed", False):  # a group's device is destroyed with the group
+                lib.mtr_device_destroy(self._h)
             self._h = None
 
     def __enter__(self):
@@ -546,4 +560,89 @@ class Frame:
     def close(self):
         if self._h:
             lib.mtr_frame_destroy(self._h)
+            self._h = None
+
+
+class Group:
+    """One host thread, N devices (include/mtr.h: mtr_group_*): rank r is a Device on hip_devices[r]; a group frame is one
+    sharded Frame per rank, and ending it gathers every part's colour into one image on rank 0's device."""
+
+    def __init__(self, hip_devices: Sequence[int]):
+        ids = np.ascontiguousarray(hip_devices, dtype=np.int32)
+        h = C.c_void_p()
+        rc = lib.mtr_group_create(_p(ids), ids.size, C.byref(h))
+        if rc:
+            raise MtrError(rc, (lib.mtr_group_last_error(None) or b"").decode())
+        self._h = h
+        self.devices = []
+        for r in range(lib.mtr_group_size(h)):
+            d = Device.__new__(Device)
+            d._h, d._borrowed = C.c_void_p(lib.mtr_group_device(h, r)), True
+            self.devices.append(d)
+
+    def __len__(self):
+        return len(self.devices)
+
+    def device(self, rank: int) -> Device:
+        return self.devices[rank]
+
+    def check(self, rc: int):
+        if rc:
+            raise MtrError(rc, (lib.mtr_group_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mtr_group_destroy(self._h)
+            self._h = None
+            for d in self.devices:
+                d._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class GroupFrame:
+    """begin -> draw into part(r) with rank r's models / batches -> end() -> color()"""
+
+    def __init__(self, group: Group, width: int, height: int, clear_rgba=(1.0, 1.0, 1.0, 1.0), clear_depth: float = 1.0,
+                 own_map: int = OWN_INTERLEAVED, param: int = 0, band_rows=None):
+        c = _f32(clear_rgba, 4)
+        br = None if band_rows is None else np.ascontiguousarray(band_rows, dtype=np.uint32)
+        if br is not None and br.size != len(group) + 1:
+            raise MtrError(MTR_E_INVALID, "band_rows needs world + 1 entries")
+        h = C.c_void_p()
+        group.check(lib.mtr_group_frame_begin(group._h, width, height, _p(c), clear_depth, own_map, param, _p(br), C.byref(h)))
+        self.group, self._h, self.w, self.h = group, h, width, height
+        self.parts = []
+        for r in range(len(group)):
+            f = Frame.__new__(Frame)
+            f.dev, f._h, f.w, f.h = group.device(r), None, width, height  # _h None: Frame.close() never destroys a part
+            f._part = C.c_void_p(lib.mtr_group_frame_part(h, r))
+            self.parts.append(f)
+
+    def part(self, rank: int) -> "Frame":
+        """rank's frame with its handle live for the draw calls (owned by the group frame)"""
+        f = self.parts[rank]
+        f._h = f._part
+        return f
+
+    def end(self):
+        self.group.check(lib.mtr_group_frame_end(self._h))
+
+    def color(self) -> np.ndarray:
+        out = np.zeros((self.h, self.w, 4), dtype=np.uint8)
+        self.group.check(lib.mtr_group_frame_read_color(self._h, _p(out), out.size))
+        return out
+
+    def color_devptr(self) -> int:
+        return int(lib.mtr_group_frame_color_devptr(self._h) or 0)
+
+    def close(self):
+        if self._h:
+            for f in self.parts:
+                f._h = None
+            lib.mtr_group_frame_destroy(self._h)
             self._h = None

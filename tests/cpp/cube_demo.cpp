@@ -2,6 +2,7 @@
 #include "mtr.hpp"
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 int main() {
     static const float verts[24] = {1, 1, -1, 1, -1, -1, 1, 1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1};
@@ -26,7 +27,22 @@ int main() {
         frame.end();
         mtr_frame_stats s = frame.stats();
         std::printf("tris_in=%llu tris_setup=%llu\n", (unsigned long long)s.tris_in, (unsigned long long)s.tris_setup);
-        return (s.tris_in == 12 && s.tris_setup == 6) ? 0 : 1;
+        if (s.tris_in != 12 || s.tris_setup != 6) return 1;
+        std::vector<uint8_t> one(256 * 256 * 4), gathered(256 * 256 * 4);
+        frame.read_color(one.data(), one.size());
+        // the same cube through a group of two ranks (both on card 0), bands of bin rows: the gathered image is the same image
+        mtr::Group group({0, 0});
+        mtr::Model m0(group.device(0), verts, sizeof verts, idx, 36, {p}, {l}, {-1}, {}, {3});
+        mtr::Model m1(group.device(1), verts, sizeof verts, idx, 36, {p}, {l}, {-1}, {}, {3});
+        {
+            mtr::GroupFrame gf(group, 256, 256, clear, 1.0f, MTR_OWN_BANDS);
+            m0.render(gf.part(0), vp);
+            m1.render(gf.part(1), vp);
+            gf.end();
+            gf.read_color(gathered.data(), gathered.size());
+        }
+        std::printf("group image %s\n", one == gathered ? "matches" : "DIFFERS");
+        return one == gathered ? 0 : 3;
     } catch (const mtr::Error& e) {
         std::fprintf(stderr, "%s\n", e.what());
         return e.code == MTR_E_HIP ? 77 : 2;  // 77: no GPU here

@@ -55,3 +55,19 @@ def test_no_rank_skips_a_collective_under_thread_sanitizer(tmp_path):
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
     assert "handed=1800" in r.stdout and "agreed_status=4" in r.stdout and 'rank1_error="reported"' in r.stdout, r.stdout
+
+
+def test_group_gather_under_address_sanitizer(tmp_path):
+    """mtr_group_* (csrc/mtr_group.cpp) over the stub runtime: groups of 1-5 ranks, odd frame sizes, every ownership map,
+    explicit bands with empty ranks, parts that "overflow" and are re-run; the stub pack / unpack move a byte derived from
+    the bin id, so the gathered image is right only if every shard landed at its rank's offset (tests/cpp/group_asan.cpp)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "group_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-w",
+                           "-I", os.path.join(ROOT, "tests", "cpp", "hip_stub"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "group_asan.cpp"), "-o", exe, "-lz"])
+    r = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-3000:])
+    out = dict(t.split("=") for t in r.stdout.split())
+    assert int(out["frames"]) == 360 and int(out["reruns"]) > 20, r.stdout
