@@ -62,9 +62,10 @@ struct Rec {
     RecHdr h;
 };
 
-// back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill
+// back-face cull (front = CCW, cull = Back: src/model.rs:252), pixel-centre bbox, record fill.
+// *small (when asked for): the triangle is a candidate for sample_cull below.
 __device__ __forceinline__ bool setup_tri(const PV& a, const PV& b_in, const PV& c_in, uint32_t W, uint32_t H, uint32_t mat,
-                                          uint32_t cull, Rec& r) {
+                                          uint32_t cull, Rec& r, bool* small = nullptr) {
     if (!((a.flags & b_in.flags & c_in.flags) & 2)) return false;
     long long A2 = (long long)(c_in.X - a.X) * (long long)(b_in.Y - a.Y) - (long long)(b_in.X - a.X) * (long long)(c_in.Y - a.Y);
     // cull back (the reference) / none / front (material state): a kept back face is set up with b and c exchanged
@@ -79,6 +80,7 @@ __device__ __forceinline__ bool setup_tri(const PV& a, const PV& b_in, const PV&
     px0 = max(px0, 0); py0 = max(py0, 0);
     px1 = min(px1, (int32_t)W - 1); py1 = min(py1, (int32_t)H - 1);
     if (px0 > px1 || py0 > py1) return false;
+    if (small) *small = ((xmax - xmin) | (ymax - ymin)) < 512;  // under 2 px across: its bbox holds at most 2 x 2 pixel centres
     r.h.bx0 = (uint16_t)(px0 >> MTR_BIN_SHIFT); r.h.bx1 = (uint16_t)(px1 >> MTR_BIN_SHIFT);
     r.h.by0 = (uint16_t)(py0 >> MTR_BIN_SHIFT); r.h.by1 = (uint16_t)(py1 >> MTR_BIN_SHIFT);
     r.a.X0 = a.X; r.a.Y0 = a.Y; r.a.X1 = b.X; r.a.Y1 = b.Y; r.a.X2 = c.X; r.a.Y2 = c.Y;
@@ -87,6 +89,54 @@ __device__ __forceinline__ bool setup_tri(const PV& a, const PV& b_in, const PV&
     r.b.up0 = a.up; r.b.up1 = b.up; r.b.up2 = c.up;
     r.b.vp0 = a.vp; r.b.vp1 = b.vp; r.b.vp2 = c.vp;
     r.b.pad0 = r.b.pad1 = r.b.pad2 = 0.0f;
+    return true;
+}
+
+// Exact coverage of the (<= 2 x 2) pixel centres in the bbox of a triangle under 2 px across, with the tile kernels' inside test bit for bit: E_i(S) =
+// dy (Sx - Xa) - dx (Sy - Ya) + (top-left ? 0 : -1) >= 0 for the three edges, which with (u_k, v_k) = S - P_k is
+// u_b v_a - u_a v_b (exact in i32 at this size); a pixel to the right adds 256 dy, one down subtracts 256 dx.  Returns false
+// when no centre is covered: the triangle is set up -- it counts in tris_setup like any triangle whose bbox holds a pixel
+// centre (SPEC.md defines the statistic by the bbox) -- but nothing downstream could produce a fragment from it, so it gets
+// no record and no queue entry.  Otherwise the bin rectangle shrinks to the covered centres: a covered pair seldom
+// straddles two bins.  On the instanced configs two thirds of the set-up triangles go (C5: 4.04 M -> 1.25 M queue entries).
+#ifndef MTR_SAMPLE_CULL
+#define MTR_SAMPLE_CULL 1
+#endif
+#ifndef MTR_SAMPLE_FRAC
+#define MTR_SAMPLE_FRAC 2u  // run the test in a wave when small triangles are at least 1 / MTR_SAMPLE_FRAC of what it set up
+#endif
+__device__ __forceinline__ bool sample_cull(Rec& r, uint32_t W, uint32_t H) {
+    // the bbox of pixel centres again (setup_tri), here only for the waves that run the test: <= 2 x 2 centres at this size
+    const int32_t xmin = min(r.a.X0, min(r.a.X1, r.a.X2)), xmax = max(r.a.X0, max(r.a.X1, r.a.X2));
+    const int32_t ymin = min(r.a.Y0, min(r.a.Y1, r.a.Y2)), ymax = max(r.a.Y0, max(r.a.Y1, r.a.Y2));
+    const int32_t px0 = max((xmin + 127) >> 8, 0), py0 = max((ymin + 127) >> 8, 0);
+    const bool two_x = min((xmax - 128) >> 8, (int32_t)W - 1) > px0, two_y = min((ymax - 128) >> 8, (int32_t)H - 1) > py0;
+    const int32_t Sx = px0 * 256 + 128, Sy = py0 * 256 + 128;
+    const int32_t u[3] = {Sx - r.a.X0, Sx - r.a.X1, Sx - r.a.X2}, v[3] = {Sy - r.a.Y0, Sy - r.a.Y1, Sy - r.a.Y2};
+    int32_t e[3], ex[3], ey[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int ia = (i + 1) % 3, ib = (i + 2) % 3;
+        const int32_t ndx = u[ib] - u[ia], dy = v[ia] - v[ib];  // -dx, dy of the edge; |dx|, |dy| < 2^10
+        // top-left (dy > 0, or dy == 0 and dx < 0)  <=>  dy * 4096 - dx > 0; the bias is 0 for such an edge, -1 otherwise
+        const int32_t bias = (((dy << 12) + ndx) - 1) >> 31;
+        e[i] = __mul24(u[ib], v[ia]) - __mul24(u[ia], v[ib]) + bias;
+        ex[i] = dy << 8; ey[i] = ndx << 8;
+    }
+    const bool m00 = (e[0] | e[1] | e[2]) >= 0;
+    bool m10 = false, m01 = false, m11 = false;
+    if (__ballot(two_x || two_y)) {  // some lane's bbox holds a second column or row (a sub-pixel mesh: seldom)
+        m10 = two_x && ((e[0] + ex[0]) | (e[1] + ex[1]) | (e[2] + ex[2])) >= 0;
+        m01 = two_y && ((e[0] + ey[0]) | (e[1] + ey[1]) | (e[2] + ey[2])) >= 0;
+        m11 = two_x && two_y && ((e[0] + ex[0] + ey[0]) | (e[1] + ex[1] + ey[1]) | (e[2] + ex[2] + ey[2])) >= 0;
+    }
+    if (!(m00 || m10 || m01 || m11)) return false;  // r.h keeps the bins of the bbox: a sharded rank counts it if it owns one
+    if (two_x || two_y) {
+        const int32_t qx0 = (m00 || m01) ? px0 : px0 + 1, qx1 = (m10 || m11) ? px0 + 1 : px0;
+        const int32_t qy0 = (m00 || m10) ? py0 : py0 + 1, qy1 = (m01 || m11) ? py0 + 1 : py0;
+        r.h.bx0 = (uint16_t)(qx0 >> MTR_BIN_SHIFT); r.h.bx1 = (uint16_t)(qx1 >> MTR_BIN_SHIFT);
+        r.h.by0 = (uint16_t)(qy0 >> MTR_BIN_SHIFT); r.h.by1 = (uint16_t)(qy1 >> MTR_BIN_SHIFT);
+    }
     return true;
 }
 
@@ -271,6 +321,8 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 
     Rec r0, r1;
     uint32_t n_out = 0;   // records held in r0 / r1
+    bool empty = false;   // set up, covers no pixel centre: counted, not recorded (sample_cull)
+    bool small = false;   // a candidate for sample_cull (setup_tri)
     // guard-band clipping (SPEC.md 5.3): a polygon with a vertex the rasteriser cannot take (w <= 0, or beyond +-2^20 px)
     // is clipped against |x| <= 64 w, |y| <= 64 w and may fan into up to six triangles; its lane keeps the polygon (in
     // scratch) and writes the records in a second pass, once every lane's place in the chunk's run is known
@@ -284,7 +336,7 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 #endif
     if (tri) {
         if (!((f_or >> 2) & OC_ZN) && (f_and & 2u)) {
-            if (setup_tri(ta, tb, tc, W, H, mat, pr.cull, r0)) n_out = 1;
+            if (setup_tri(ta, tb, tc, W, H, mat, pr.cull, r0, &small)) n_out = 1;
         } else {
             // near-plane clip (z >= 0) and / or guard-band clip: rare, re-shades the three vertices in clip space
             const uint32_t ia = vid2, ib = odd ? vid : vid1, ic = odd ? vid1 : vid;
@@ -342,6 +394,18 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
 
     // ---- sharded frames: a rank keeps only the triangles whose bin rectangle holds one of its bins, so records,
     //      queue traffic and binning work shrink with the shard.  Relative order is preserved.
+#if MTR_SAMPLE_CULL
+    // the coverage test costs every wave that runs it the same ~40 instructions: worth them where most of what the wave
+    // set up is small (the instanced configs), not where a few lanes are (the headline model: 4 % of its entries go)
+    {
+        const uint64_t sm = __ballot(small);
+        if (sm && (uint32_t)__popcll(sm) * MTR_SAMPLE_FRAC >= (uint32_t)__popcll(__ballot(n_out != 0u)) && small && !sample_cull(r0, W, H)) {
+            n_out = 0;
+            empty = true;
+        }
+    }
+#endif
+    if (P.fb.own.world > 1 && empty) empty = rect_owned_any(P.fb.own, r0.h.bx0, r0.h.by0, r0.h.bx1, r0.h.by1, P.fb.nbx);
     if (P.fb.own.world > 1 && n_out) {
         const bool k0 = rect_owned_any(P.fb.own, r0.h.bx0, r0.h.by0, r0.h.bx1, r0.h.by1, P.fb.nbx);
         const bool k1 = n_out == 2 && rect_owned_any(P.fb.own, r1.h.bx0, r1.h.by0, r1.h.bx1, r1.h.by1, P.fb.nbx);
@@ -354,6 +418,7 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     const uint32_t n_res = n_poly ? n_poly - 2u : n_out;
     uint32_t rank, total;
     const uint64_t b1 = __ballot(n_out >= 1), b2 = __ballot(n_out == 2);
+    const uint32_t n_empty = (uint32_t)__popcll(__ballot(empty));
     if (!__ballot(n_poly != 0)) {
         const uint64_t lt = (1ull << lane) - 1ull;
         rank = (uint32_t)__popcll(b1 & lt) + (uint32_t)__popcll(b2 & lt);
@@ -375,7 +440,8 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
             P.fb.chunk_info[gid] = ci;
         }
         const uint32_t nrec = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
-        if (total && nrec) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], nrec);  // statistics only
+        const uint32_t nset = (total ? nrec : 0u) + n_empty;
+        if (nset) atomicAdd(&P.fb.counters[MTR_CTR(CTR_REC, gid)], nset);  // statistics only (tris_setup)
     }
     total = __builtin_amdgcn_readfirstlane(total);
     if (total == 0) return;

@@ -8,6 +8,6 @@ for n in 1 2 3 4 5 6; do
 done
 wait
 for n in 1 2 3 4 5 6; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr_abl$n.so /tmp/k_geom_abl$n.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o mtr_files.o -lz
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr_abl$n.so /tmp/k_geom_abl$n.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o mtr_files.o mtr_group.o -lz
 done
 ls -la ../libmtr_abl*.so

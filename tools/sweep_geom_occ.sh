@@ -5,7 +5,7 @@ if [ "$1" = build ]; then
   cd mt_renderer_amd/csrc
   FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function -Wno-missing-braces"
   for n in 4 5 6 7 8; do /opt/rocm/bin/hipcc $FL -DGEOM_OCC=$n -c k_geom.hip -o /tmp/k_geom_occ$n.o & done; wait
-  for n in 4 5 6 7 8; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr_gocc$n.so /tmp/k_geom_occ$n.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o mtr_files.o -lz; done
+  for n in 4 5 6 7 8; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmtr_gocc$n.so /tmp/k_geom_occ$n.o k_bin.o k_tile.o k_tile_vis.o k_texture.o k_shard.o mtr_api.o mtr_files.o mtr_group.o -lz; done
   ls ../libmtr_gocc*.so
 else
   for n in 4 5 6 7 8; do
