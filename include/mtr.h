@@ -81,7 +81,8 @@ typedef struct mtr_frame mtr_frame;
 /* per-frame counters (device side, read back by mtr_frame_get_stats) */
 typedef struct mtr_frame_stats {
     uint64_t tris_in;     /* input triangles, SURVEY 8(d) definition */
-    uint64_t tris_setup;  /* triangles that survived clip / cull / empty-bbox (sharded frame: and touch a bin of this rank) */
+    uint64_t tris_setup;  /* triangles that survived clip / cull / empty-bbox (sharded frame: and touch a bin of this rank); one that
+                             covers no pixel centre is counted here and queued nowhere: bin_entries counts what is queued */
     uint64_t bin_entries; /* (triangle, 16x16 bin) pairs */
     uint64_t segments;    /* per-bin ordered runs */
     uint32_t width, height, nbins, ndraws;
