@@ -509,6 +509,16 @@ __device__ __forceinline__ void geom_chunk(const GeomParams& P, uint32_t inst, u
     }
 }
 
+// Length of the instance list: a SCALAR load of a uniform address.  Written as `count ? *count : ninst` the compiler selects
+// between the two ADDRESSES (the kernel argument's and the counter's) and loads through a flat VECTOR instruction -- the first
+// thing every wave of a sharded launch waits for, the ones of dead instance slots included (ISA of round 3: flat_load_dword
+// + v_cmp + s_and_saveexec).  Hiding the argument's value from that transformation leaves a branch and an s_load_dword.
+__device__ __forceinline__ uint32_t live_instances(const uint32_t* count, uint32_t ninst) {
+    asm("" : "+s"(ninst));
+    if (count) ninst = *count;
+    return ninst;
+}
+
 #ifndef GEOM_OCC
 #define GEOM_OCC 8  // waves per SIMD the register allocator must leave room for: 64 VGPRs.  Rounds 1-2 ran at 6 (80 VGPRs,
                     // the vertex stage's live ranges spilled below that); with the vertex stage feeding LDS the kernel fits 64
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(256, OCC) void k_geom(GeomParams P) {
     // (Fetching the group's 16 chunk descriptors together with the mask, lane = chunk, to take one load off the chain in
     // front of the vertex work: 192 vs 189 us, no gain.)
     const uint32_t nxq = P.work_nx * 4u, ii = blockIdx.x / nxq, xq = blockIdx.x - ii * nxq, x = xq >> 2, q = xq & 3u;  // slots [0, grid / nxq)
-    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    const uint32_t nlive = live_instances(P.inst_count, P.ninst);
     if (ii >= nlive) return;  // before touching anything else: a dead slot must cost no memory traffic
     // the mask through a SCALAR load (the aligned dword that holds it: a 16-bit load of a uniform address is still a
     // vector-memory load, ~1 us under load, and the instance-list load waited behind it)
@@ -603,7 +613,7 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t split = min(P.work_nx, MTR_GEOM_REST_SPLIT);
     const uint32_t ii = P.work_slot_base + blockIdx.x / split;
-    const uint32_t nlive = P.inst_count ? *P.inst_count : P.ninst;
+    const uint32_t nlive = live_instances(P.inst_count, P.ninst);
     if (ii >= nlive) return;
     const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
     stage_palette(P, inst, s_pal, s_M);
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256, LDS_COMP ? 4 : 8) void k_cull_chunks(ChunkCull
     BoneBox bx = {};
     const bool tests = has && !unbounded && sub < n;
     if (tests) bx = P.boxes[first + sub];
-    const uint32_t nlive = P.strad ? P.inst_count[1] : (P.inst_count ? *P.inst_count : P.ninst);
+    const uint32_t nlive = P.strad ? P.inst_count[1] : live_instances(P.inst_count, P.ninst);
     for (uint32_t si = blockIdx.y; si < nlive; si += gridDim.y) {
         const uint32_t ii = P.strad ? P.strad[si] : si;  // the instance's slot: where its masks go
         const uint32_t inst = P.inst_list ? P.inst_list[ii] : ii;
@@ -798,6 +808,15 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
         // every one of them leaves at once; when a rank does keep more, they are exact and only a little slower.
         uint32_t slots = p.ninst;
         if (p.inst_count && p.fb.own.world > 1) slots = std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world + 64u);  // 64 more cost 3 us
+        // ... unless a recent frame of the same batch under the same ownership reported its list length (through its tile kernel, TileParams::hint_out):
+        // a dead slot is 204 workgroups = 816 waves that launch, load the length and leave, and the chip launches ~2.6
+        // waves per cycle: the 98 k idle workgroups of C5 as rank 0 of 2 cost 62 us of 461, the 30 k of rank 3 of 8 19 us of
+        // 127 (kernel trace, keep-everything ablation against the normal run).  An eighth more than reported + 4; whatever
+        // a moving camera adds beyond that goes through the second launch, as before.
+        if (p.inst_count && (p.slots_hint & 0x80000000u)) {
+            const uint32_t h = p.slots_hint & 0x7FFFFFFFu;
+            slots = std::min<uint32_t>(p.ninst, h + h / 8u + 4u);
+        }
         // the second launch costs ~4 us of stream time even when every one of its workgroups leaves at once: when the slots it
         // would cover are few (idle workgroups at ~0.2 ns each: 20 000 of them = 4 us), the full-rate launch takes them all
         if ((uint64_t)(p.ninst - slots) * p.work_nx * 4u <= 20000u) slots = p.ninst;
@@ -830,6 +849,8 @@ void mtr_launch_cull_chunks(const ChunkCullParams& p, hipStream_t s) {
     // instance slots: the kernel strides over the (possibly compacted) instance list; twice the rank's fair share
     uint32_t ny = p.ninst;
     if (p.inst_count && p.fb.own.world > 1) ny = std::max<uint32_t>(1u, std::min<uint32_t>(p.ninst, (2u * p.ninst + p.fb.own.world - 1) / p.fb.own.world));
+    // the straddlers a recent frame of the batch reported (the kernel strides over the list: any ny is correct)
+    if (p.strad && (p.strad_hint & 0x80000000u)) ny = std::max<uint32_t>(1u, std::min<uint32_t>(p.ninst, (p.strad_hint & 0x7FFFFFFFu) + (p.strad_hint & 0x7FFFFFFFu) / 8u + 2u));
     ny = std::min<uint32_t>(ny, 65535u);
     const uint32_t ncomp = (p.palettes && p.npal) ? p.npal + 1u : 1u;
     if (p.comp) hipLaunchKernelGGL(mtr::k_cull_chunks<false>, dim3((p.nchunks + 15) / 16, ny), dim3(256), 0, s, p);

@@ -149,6 +149,13 @@ struct mtr_device {
     // slots the full-rate sharded geometry launch covers (tests force k_geom_rest with it); 0xFFFFFFFF / 0: not set
     uint32_t cull_debug = 0xFFFFFFFFu;
     uint32_t geom_slots = 0;
+    // launch-size feedback of sharded batch draws (TileParams::hint_out): two words of pinned host memory per hint slot; a
+    // batch takes a slot at its first culled draw and gives it back when it is destroyed.  A late write of a frame still
+    // in flight into a slot that has changed hands only mis-sizes a launch (the second geometry launch covers the rest).
+    static constexpr uint32_t kHintSlots = 256;
+    uint32_t* hint_host = nullptr;
+    uint32_t* hint_dev = nullptr;
+    bool hint_used[kHintSlots] = {};
 
     // Tile-kernel bin order across the 8 XCDs.  One contiguous eighth of the bins per XCD keeps the records of
     // neighbouring bins in one L2 and gives the shortest stand-alone kernel (48.9 us), but the XCDs that own the empty top
@@ -273,6 +280,8 @@ struct mtr_batch {
     hipEvent_t ready = nullptr;  // the uploads (copy stream); frames that draw the batch wait on it
     uint64_t last_frame = 0;     // last frame that drew it: its buffers are freed only once that frame has left the GPU
     bool used = false;
+    int hint_slot = -1;          // mtr_device::hint_host slot, or -1
+    uint64_t hint_key = 0;       // the ownership (table, rank) the slot's numbers were reported under
 };
 
 struct BatchDeleter {
@@ -779,6 +788,10 @@ int32_t mtr_device_create_on_stream(int32_t hip_device, void* hip_stream, mtr_de
                                   hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&d->status_dev), d->status_host, 0));
     for (uint32_t i = 0; i < mtr_device::kMaxInflight; i++) { d->status_host[i] = 0x80000000u; d->status_checked[i] = true; }
+    HIPCHK(nullptr, hipHostMalloc(reinterpret_cast<void**>(&d->hint_host), mtr_device::kHintSlots * 2 * sizeof(uint32_t),
+                                  hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(nullptr, hipHostGetDevicePointer(reinterpret_cast<void**>(&d->hint_dev), d->hint_host, 0));
+    memset(d->hint_host, 0, mtr_device::kHintSlots * 2 * sizeof(uint32_t));
     if (const char* e = getenv("MTR_VIS_WAVES")) {
         const long v = strtol(e, nullptr, 10);
         if (v == 2 || v == 4 || v == 8) d->vis_waves = (uint32_t)v;
@@ -838,6 +851,7 @@ void mtr_device_destroy(mtr_device* d) {
     }
     if (d->own_stream) (void)hipStreamDestroy(d->stream);
     if (d->status_host) (void)hipHostFree(d->status_host);
+    if (d->hint_host) (void)hipHostFree(d->hint_host);
     delete d;
 }
 
@@ -1219,6 +1233,7 @@ void mtr_batch_destroy(mtr_batch* b) {
     // destroys the batches its frames own while the render thread submits: submit_mu guards the list and the index.
     std::lock_guard<std::mutex> submit_lock(d->submit_mu);
     const bool busy = b->used && d->frames_submitted <= b->last_frame + d->max_inflight;
+    if (b->hint_slot >= 0) { d->hint_used[b->hint_slot] = false; d->hint_host[2 * b->hint_slot] = d->hint_host[2 * b->hint_slot + 1] = 0u; }
     for (void* p : {(void*)b->d_model_mats, (void*)b->d_palettes})
         if (p) {
             if (busy) d->garbage.push_back({p, b->last_frame});
@@ -1733,6 +1748,8 @@ static int32_t run_frame(mtr_frame* f) {
         if (!fb.direct) HIPCHK(d, hipMemsetAsync(sl.chunk_info, 0, total_chunks * sizeof(ChunkInfo), sg));
     }
     if (prof) HIPCHK(d, hipEventRecord(f->ev[0], sg));
+    uint32_t nhint = 0;  // batch draws whose culling counters this frame's tile kernel reports to the host (launch sizing)
+    uint16_t hint_word[4] = {}, hint_slot[4] = {};
     uint32_t chunk_base = 0;
     for (size_t di = 0; di < f->draws.size(); di++) {
         Draw& dr = f->draws[di];
@@ -1784,6 +1801,24 @@ static int32_t run_frame(mtr_frame* f) {
             cc.comp = inst_cnt ? sl.comp + comp_off[di] : nullptr;
             cc.work_mask = sl.work_mask + work_off[di];
             cc.keep_all = (fb.own.cull == 3u || fb.own.cull == 4u) ? 1u : 0u;
+            if (inst_cnt && dr.batch && !dr.owned_batch) {
+                // launch sizes from what a recent frame of this batch kept under the same ownership (k_geom.hip); a camera that
+                // moves changes the count gradually: the margin and the second geometry launch take what the hint misses
+                mtr_batch* b = dr.batch;
+                if (b->hint_slot < 0)
+                    for (uint32_t i = 0; i < mtr_device::kHintSlots; i++)
+                        if (!d->hint_used[i]) { d->hint_used[i] = true; b->hint_slot = (int)i; b->hint_key = 0; break; }
+                if (b->hint_slot >= 0) {
+                    uint64_t key = 0xcbf29ce484222325ull;  // FNV-1a over what the kept set depends on
+                    auto mix = [&](const void* p, size_t n) { for (size_t i = 0; i < n; i++) key = (key ^ static_cast<const uint8_t*>(p)[i]) * 0x100000001b3ull; };
+                    const void* own_id = f->own;
+                    mix(&own_id, sizeof own_id); mix(&f->shard_rank, sizeof f->shard_rank); mix(&fb.own.cull, sizeof fb.own.cull);
+                    volatile uint32_t* hw = d->hint_host + 2 * b->hint_slot;
+                    if (key != b->hint_key) { b->hint_key = key; hw[0] = hw[1] = 0u; }  // other bands, another rank: start over
+                    gp.slots_hint = hw[0]; cc.strad_hint = hw[1];
+                    if (nhint < 4 && di * MTR_CULL_CTR_WORDS < 0xFFFFu) { hint_word[nhint] = (uint16_t)(di * MTR_CULL_CTR_WORDS); hint_slot[nhint++] = (uint16_t)b->hint_slot; }
+                }
+            }
             mtr_launch_cull_chunks(cc, sg);
             HIPCHK(d, hipGetLastError());
             gp.work_mask = cc.work_mask; gp.work_nx = (gp.nchunks + 15u) / 16u;
@@ -1834,11 +1869,14 @@ static int32_t run_frame(mtr_frame* f) {
     }
     if (fb.own.cull && fb.own.own_count) {  // this frame's tile kernel clears the slot's culling counters for the next one
         tp.zero_words = sl.inst_count; tp.zero_nwords = (uint32_t)ndraws * MTR_CULL_CTR_WORDS;
+        tp.hint_out = d->hint_dev; tp.nhint = nhint;
+        for (uint32_t k = 0; k < nhint; k++) { tp.hint_word[k] = hint_word[k]; tp.hint_slot[k] = hint_slot[k]; }
         sl.cull_counts_dirty = false;
         sl.ctr_clean_draws = (uint32_t)ndraws;  // what a frame with more draws than this one finds beyond is stale
     }
     f->stats.tile_kernel = use_vis ? MTR_TILE_VISIBILITY : (mixed ? MTR_TILE_MIXED : MTR_TILE_ORDERED);
     if (use_vis || mixed) { mtr_launch_tile_vis(tp, any_textured, st); HIPCHK(d, hipGetLastError()); }
+    if (mixed) tp.nhint = 0;  // the visibility kernel of a mixed frame has reported (and cleared) the counters: the second kernel would report zeros
     if (!use_vis) { mtr_launch_tile(tp, any_textured, st); HIPCHK(d, hipGetLastError()); }
     // a rank without a bin launches no tile workgroup: nobody else would publish the (clean) status
     if (fb.own.own_count == 0) __atomic_store_n(&d->status_host[sidx], 0x80000000u, __ATOMIC_RELEASE);

@@ -294,6 +294,7 @@ struct GeomParams {
     uint32_t small_draw;       // the draw does not fill the GPU: the build of k_geom that leaves a wave slot per SIMD free
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instance slot ii is instance ii
     const uint32_t* inst_count;  // length of inst_list (device), or nullptr: ninst
+    uint32_t slots_hint;         // 0, or 0x80000000 | the length a recent frame of this batch reported (launch sizing only)
     const float* model_mats;  // ninst*16 or nullptr
     const float* palettes;    // per instance npal*16 floats (stride pal_stride floats) or nullptr
     uint32_t npal, pal_stride;
@@ -328,6 +329,13 @@ struct TileParams {
     // the slot's culling counters (instance-list and work-list lengths), zeroed here for the slot's next frame
     uint32_t* zero_words;
     uint32_t zero_nwords;
+    // feedback for the NEXT frames' launch sizes (k_geom.hip: mtr_launch_geom): before culling counter word hint_word[k] + j
+    // (j = 0: instance-list length of a batch draw, 1: its straddlers) is zeroed, 0x80000000 | its value is stored to
+    // hint_out[2 * hint_slot[k] + j] -- pinned host memory, like host_status.  (Stored from k_geom itself, ahead of its
+    // scalar loads, the store made the compiler turn every one of them into a vector load: 461 -> 686 us on C5 as rank 0 of 2.)
+    uint32_t* hint_out;
+    uint32_t nhint;
+    uint16_t hint_word[4], hint_slot[4];
 };
 
 // launchers (defined in the .hip files, called from mtr_api.cpp)
@@ -378,6 +386,7 @@ struct ChunkCullParams {
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instances 0 .. ninst-1
     const uint32_t* inst_count;
     const uint32_t* strad;       // slots (indices into inst_list) of the instances to test, length inst_count[1]; nullptr: every slot
+    uint32_t strad_hint;         // 0, or 0x80000000 | the straddler count a recent frame of this batch reported (launch sizing only)
     const float* model_mats;
     const float* palettes;
     uint32_t npal, pal_stride;

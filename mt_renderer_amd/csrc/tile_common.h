@@ -9,7 +9,13 @@ namespace mtr {
 // every workgroup of a tile kernel clears its slice of the counter block the next frame on these framebuffers will use
 __device__ __forceinline__ void zero_next_counters(const TileParams& P) {
     if (P.zero_words)
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.zero_nwords; i += gridDim.x * blockDim.x) P.zero_words[i] = 0u;
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < P.zero_nwords; i += gridDim.x * blockDim.x) {
+            for (uint32_t k = 0; k < P.nhint; k++)  // the thread that clears a word the host wants to see publishes it first
+                if (i - P.hint_word[k] < 2u)
+                    __hip_atomic_store(&P.hint_out[2u * P.hint_slot[k] + (i - P.hint_word[k])], 0x80000000u | P.zero_words[i], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+            P.zero_words[i] = 0u;
+        }
     if (!P.zero_next) return;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < (uint32_t)CTR_NUM; i += gridDim.x * blockDim.x) P.zero_next[i] = 0u;
 }
