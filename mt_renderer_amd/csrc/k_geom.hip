@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_geom_rest(GeomParams P) {
     __shared__ float s_M[16];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t split = min(P.work_nx, MTR_GEOM_REST_SPLIT);
+    const uint32_t split = min(P.work_nx, P.rest_split);
     const uint32_t ii = P.work_slot_base + blockIdx.x / split;
     const uint32_t nlive = live_instances(P.inst_count, P.ninst);
     if (ii >= nlive) return;
@@ -826,7 +826,9 @@ void mtr_launch_geom(const GeomParams& p, hipStream_t s) {
         if (slots < p.ninst) {
             GeomParams r = p;
             r.work_slot_base = slots;
-            dim3 rest((p.ninst - slots) * std::min<uint32_t>(p.work_nx, MTR_GEOM_REST_SPLIT));
+            // sized by a recent frame's count the slots beyond are empty but for what a camera move added: a quarter of the workgroups
+            r.rest_split = (p.inst_count && (p.slots_hint & 0x80000000u) && !p.slots_override) ? MTR_GEOM_REST_SPLIT / 4u : MTR_GEOM_REST_SPLIT;
+            dim3 rest((p.ninst - slots) * std::min<uint32_t>(p.work_nx, r.rest_split));
             if (p.fb.direct && p.fb.unordered) hipLaunchKernelGGL((mtr::k_geom_rest<2>), rest, dim3(256), lds, s, r);
             else if (p.fb.direct) hipLaunchKernelGGL((mtr::k_geom_rest<1>), rest, dim3(256), lds, s, r);
             else hipLaunchKernelGGL((mtr::k_geom_rest<0>), rest, dim3(256), lds, s, r);

@@ -290,6 +290,7 @@ struct GeomParams {
     const uint16_t* work_mask;   // 4-byte aligned, an even number of masks allocated
     uint32_t work_nx;          // groups of 16 chunks per instance = ceil(nchunks / 16)
     uint32_t work_slot_base;   // k_geom_rest: the first instance slot of its launch
+    uint32_t rest_split;       // k_geom_rest: workgroups per instance slot (each walks every rest_split-th mask of the instance)
     uint32_t slots_override;   // 0, or the number of instance slots the full-rate launch covers (MTR_GEOM_SLOTS, tests)
     uint32_t small_draw;       // the draw does not fill the GPU: the build of k_geom that leaves a wave slot per SIMD free
     const uint32_t* inst_list;   // from k_cull_instances, or nullptr: instance slot ii is instance ii
