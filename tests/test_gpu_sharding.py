@@ -292,3 +292,52 @@ def test_unsharded_frames_can_cull_what_is_off_the_target(gpu_device):
         gpu_device.set_culling(api.GEOM_CULL_SHARDED)
     with pytest.raises(api.MtrError):
         gpu_device.set_culling(7)
+
+
+def test_launch_sizes_from_reported_counts_survive_a_moving_camera_and_a_recycled_slot():
+    """A sharded batch draw sizes its launches by the instance counts its last frames reported (pinned host words written by
+    the tile kernel; mtr_api.cpp: hint_host).  The count is a hint: frames whose rank keeps MANY more instances than the hint
+    says -- the camera jumps from a view where a few instances reach the band to one where most of them do -- must come out
+    exactly as without it (the remainder launch takes what the hint misses), and a hint slot that changes hands when a batch
+    is destroyed must not leak a frame's worth of wrong geometry into the next batch."""
+    from mt_renderer_amd import api
+    w, h, world, rank = 640, 360, 4, 1
+    md = scene.mesh50k()  # 813 chunks: 51 mask groups per instance, so the slots a low hint leaves out are worth a second launch
+    mats, pals = scene.instance_lattice(16, 12)
+    bands = [0, 6, 12, 18, (h + 15) // 16]
+    owner = sharding.owner_map(w, h, world, sharding.BANDS, 0, bands)
+    own = owner == rank
+    cams = [scene.to_f32_colmajor(scene.reference_view_proj(w, h)),                                   # the lattice fills the frame
+            scene.to_f32_colmajor(scene.reference_view_proj(w, h, position=(-5.0, 3.5, 1.0))),      # ... slides down: few instances in band 1
+            scene.to_f32_colmajor(scene.reference_view_proj(w, h, position=(-5.0, 0.0, 6.0)))]      # ... far away: every instance near the middle rows
+    with api.Device(0) as dev:
+        model = api.Model.new(dev, md)
+
+        def frame(batch, vp, shard):
+            fr = api.Frame(dev, w, h)
+            if shard:
+                fr.set_shard(rank, world, sharding.BANDS, 0, bands)
+            fr.draw_batch(batch, vp)
+            fr.end()
+            out = fr.color(), fr.depth().view(np.uint32), fr.stats()
+            fr.close()
+            return out
+
+        batch = api.Batch(dev, model, mats, pals)
+        refs = [frame(batch, vp, False) for vp in cams]
+        kept = []
+        for k in (1, 1, 1, 1, 2, 2, 0, 0, 1, 2, 0, 1):  # four frames settle the hint low, then the jumps
+            c, d, st = frame(batch, cams[k], True)
+            assert (c[own] == refs[k][0][own]).all() and (d[own] == refs[k][1][own]).all(), k
+            kept.append(st["chunks"] - st["chunks_culled"])
+        assert max(kept) > 3 * min(kept), kept  # the views really differ in what the rank keeps
+        # a second batch takes over the first one's hint slot: its first sharded frames run with whatever the slot holds
+        batch.close()
+        mats2, pals2 = scene.instance_lattice(5, 40)
+        batch2 = api.Batch(dev, model, mats2, pals2)
+        ref2 = frame(batch2, cams[0], False)
+        for _ in range(4):
+            c, d, _ = frame(batch2, cams[0], True)
+            assert (c[own] == ref2[0][own]).all() and (d[own] == ref2[1][own]).all()
+        batch2.close()
+        model.close()
