@@ -540,16 +540,21 @@ def main():
     direct = stats["binning"] == 1
     vis = stats["tile_kernel"] == 2
     # kernel names as rocprofv3 prints them: k_geom<queue builder, culled launch, waves per SIMD it is built for (7: a draw of
-    # fewer than 65536 geometry waves)>, k_tile_vis<textured, waves per bin, order lists>
+    # fewer than 65536 geometry waves)>, k_tile_vis<textured, waves per bin, order lists, quad walk>.  The timed region's frames
+    # share the GPU with their neighbours and run the <.., false> instantiation; a frame that has the GPU to itself (the latency
+    # figure, stage_ms_serial) runs <.., true>, which walks bboxes in 2 x 2 quads: shorter alone, slower among other kernels
+    vis_waves = 2 if stats["shard_bins"] > 4096 else (4 if stats["shard_bins"] > 1536 else 8)
     names = {"geom": "k_geom<%d, %s, %d>" % (((2 if vis else 1) if direct else 0), "true" if sharded and own[0] != api.OWN_INTERLEAVED else "false",
                                              7 if stats["chunks"] < 65536 else 8),
-             "scan": "k_scan", "fill": "k_fill", "tile": ("k_tile_vis<false, %d, false>" % (2 if stats["shard_bins"] > 4096 else (4 if stats["shard_bins"] > 1536 else 8))) if vis else "k_tile<false>"}
+             "scan": "k_scan", "fill": "k_fill", "tile": ("k_tile_vis<false, %d, false, false>" % vis_waves) if vis else "k_tile<false>"}
     alg = {"geom": alg_geom, "tile": alg_tile}
     traffic_by_kernel = pmc_traffic() if world == 1 else {}
     kernels = {}
     for st in ("geom", "tile"):
         k = {"kernel": names[st], "algorithmic_bytes_per_launch": alg[st], "ms_overlapped": round(stage_ms[st], 5),
              "ms_standalone": round(stage_ms_serial[st], 5), "traffic": traffic_by_kernel.get(names[st])}
+        if st == "tile" and vis:
+            k["kernel_standalone"] = "k_tile_vis<false, %d, false, true>" % vis_waves
         k["frac_overlapped"] = round(alg[st] / (stage_ms[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         k["frac_standalone"] = round(alg[st] / (stage_ms_serial[st] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         kernels[st] = k
@@ -565,7 +570,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg[dom], "kernel_ms": round(stage_ms[dom], 5), "kernel_ms_standalone": round(stage_ms_serial[dom], 5),
                 "note": "kernel_ms > ms_per_step is stream concurrency, not an inconsistency: three frames' kernels are co-resident "
                         "on three streams, so a launch lasts longer than a step; frac uses that overlapped duration (what rocprofv3 "
-                        "--stats of this command reports), frac_standalone the kernel alone on the GPU",
+                        "--stats of this command reports), frac_standalone the kernel alone on the GPU (the visibility kernel then runs "
+                        "its quad-walk instantiation, kernels.tile.kernel_standalone)",
                 "kernels": kernels,
                 "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()},
                 "stage_ms_serial": {k: round(v, 5) for k, v in stage_ms_serial.items()},

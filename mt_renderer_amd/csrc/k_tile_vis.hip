@@ -46,14 +46,15 @@ struct VisTri {
     float z0, dz1;
     float dz2, rcpA;
     uint32_t ordk;           // submission order + 1
-    uint32_t box;            // px0 | py0 << 4 | (bw-1) << 8 | magic(bw) << 12   (k / bw = k * magic >> 16)
+    uint32_t box;            // px0 | py0 << 4 | (bw-1) << 8 | magic(iw) << 12   (k / iw = k * magic >> 16; iw: items per bbox row)
 };
 static_assert(sizeof(VisTri) == 64, "VisTri is 64 B");
 
 struct Setup {
     VisTri t;
     int4 chi;
-    int32_t npx;
+    int32_t npx;   // pixels of the triangle's bbox in this bin
+    uint32_t bhm1; // bbox height - 1
 };
 
 __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t binx0, int32_t biny0, int32_t vw, int32_t vh, Setup& s) {
@@ -95,9 +96,8 @@ __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t b
     const int32_t px0 = max(((xmin + 127) >> 8) - binx0, 0), px1 = min(((xmax - 128) >> 8) - binx0, min(MTR_BIN, vw) - 1);
     const int32_t py0 = max(((ymin + 127) >> 8) - biny0, 0), py1 = min(((ymax - 128) >> 8) - biny0, min(MTR_BIN, vh) - 1);
     const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
-    s.npx = (bw > 0 && bh > 0) ? bw * bh : 0;
-    const uint32_t ubw = (uint32_t)max(bw, 1);
-    const uint32_t magic = (65536u + ubw - 1u) / ubw;  // exact k / bw for k < 256, bw <= 16
+    s.npx = (bw > 0 && bh > 0) ? bw * bh : 0;  // pixels of the bbox in this bin; the caller turns it into work items (walk_items)
+    s.bhm1 = (uint32_t)max(bh - 1, 0);
     s.t.A0 = A[0]; s.t.B0 = B[0]; s.t.C0 = Clo[0];
     s.t.A1 = A[1]; s.t.B1 = B[1]; s.t.C1 = Clo[1];
     s.t.A2 = A[2]; s.t.B2 = B[2]; s.t.C2 = Clo[2];
@@ -105,10 +105,13 @@ __device__ __forceinline__ void setup_tri(const RecA& a, uint32_t ord, int32_t b
     s.t.z0 = a.z0; s.t.dz1 = a.z1 - a.z0; s.t.dz2 = a.z2 - a.z0;
     s.t.rcpA = 1.0f / fA2;
     s.t.ordk = ord + 1u;
-    s.t.box = (uint32_t)(px0 & 15) | ((uint32_t)(py0 & 15) << 4) | ((uint32_t)((bw - 1) & 15) << 8) | (magic << 12);
+    s.t.box = (uint32_t)(px0 & 15) | ((uint32_t)(py0 & 15) << 4) | ((uint32_t)((bw - 1) & 15) << 8);  // + magic << 12 (walk_items)
     s.chi = make_int4(Chi[0], Chi[1], Chi[2], 0);
 }
 
+#ifndef MTR_QUAD_WALK
+#define MTR_QUAD_WALK 1
+#endif
 #define STAIR_K 8u  // submission orders kept per pixel (STAIR)
 
 // one fragment that passed coverage and the z range.  STAIR: also remember its order unless the key it meets proves it
@@ -188,7 +191,7 @@ __device__ __forceinline__ float z_at(const RecA& a, int32_t px, int32_t py) {
 // VIS_WAVES: 2 for unsharded frames (see above); a sharded rank has few bins and the frame then takes as long as its
 // heaviest bin (629 triangles = 183 batches of 64 pairs on the headline scene: 23 us with two waves), so the host
 // gives such frames 4 or 8 waves per bin (mtr_launch_tile_vis).
-template <bool TEX, int VIS_WAVES, bool STAIR>
+template <bool TEX, int VIS_WAVES, bool STAIR, bool QW>
 __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams P) {
     __shared__ unsigned long long s_key[MTR_BIN * MTR_BIN];
     __shared__ uint4 s_flat[VIS_WAVES][64 * 4];              // flat-class triangles of the current pass, 64 B each
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
 
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t magic_lut = (65536u + (lane & 15u)) / ((lane & 15u) + 1u);  // lane i: ceil(65536 / (i + 1)), fetched by __shfl per pass
     const uint32_t ovf = tile_prologue(P);
     uint32_t bin;
     if (!block_to_bin(P.fb, bin, P.xcd_run)) return;  // uniform over the workgroup, before any barrier
@@ -276,7 +280,19 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
         Setup s = {};
         if (valid) setup_tri(a_cur, ord_cur, binx0, biny0, vw, vh, s);
         const bool large = (s.t.flags & 1u) != 0;
-        const uint32_t npx = (uint32_t)s.npx;
+        // The wave's work item is a (triangle, pixel of its bbox) pair, or -- when a good part of the pass's triangles have a bbox
+        // of more than four pixels -- a (triangle, 2 x 2 quad) pair: one staged record read and one index decode per four pixels,
+        // the three edge functions stepped by an add.  A pass of one-pixel boxes (the instanced configs) is cheaper pixel by pixel,
+        // a pass of the headline model's 10-pixel boxes in quads: 9 % fewer VALU and 29 % fewer LDS instructions, the kernel alone
+        // 50.4 -> 45.3 us -- and frames in flight 1.3 % SLOWER (paired builds, three runs each), so the host asks for quads only
+        // for a frame that has the GPU to itself (TileParams::quad_walk -> the QW instantiation: latency, not throughput).  Uniform
+        // over the wave.
+        const bool quads = QW && (uint32_t)__popcll(__ballot(!large && s.npx > 4)) * 4u >= (uint32_t)__popcll(__ballot(!large && s.npx > 0));
+        const uint32_t bwm1_l = (s.t.box >> 8) & 15u;
+        const uint32_t iw = (quads && !large) ? (bwm1_l >> 1) + 1u : bwm1_l + 1u, ih = (quads && !large) ? (s.bhm1 >> 1) + 1u : s.bhm1 + 1u;
+        const uint32_t npx = s.npx ? iw * ih : 0u;
+        // k / iw = k * magic >> 16, exact for k < 256 and iw <= 16: magic = ceil(65536 / iw), from the lanes' table (QW) or divided out
+        s.t.box |= (QW ? (uint32_t)__shfl((int)magic_lut, (int)(iw - 1u)) : (65536u + iw - 1u) / iw) << 12;
         // ---- lane = pixel of the bbox: triangles that need 64-bit edge functions (more than 64 px across: rare),
         //      broadcast one at a time with v_readlane ----
         for (uint64_t mb = __ballot(npx != 0 && large); mb; mb &= mb - 1) {
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                 const int32_t c2 = s.t.C2 + __mul24(s.t.A2, ox) + __mul24(s.t.B2, oy);
                 dst[0] = make_uint4((uint32_t)s.t.A0, (uint32_t)s.t.B0, (uint32_t)c0, (uint32_t)s.t.A1);
                 dst[1] = make_uint4((uint32_t)s.t.B1, (uint32_t)c1, (uint32_t)s.t.A2, (uint32_t)s.t.B2);
-                dst[2] = make_uint4((uint32_t)c2, pre, __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
+                dst[2] = make_uint4((uint32_t)c2, pre | (s.bhm1 << 16), __float_as_uint(s.t.z0), __float_as_uint(s.t.dz1));
                 // box bits 29 / 30: 1 - tl of edges 1 / 2 (flags bits 5 / 6)
                 dst[3] = make_uint4(__float_as_uint(s.t.dz2), __float_as_uint(s.t.rcpA), s.t.ordk, s.t.box | ((s.t.flags & 0x60u) << 24));
                 atomicOr(&s_start[wv][pre >> 6], 1ull << (pre & 63u));
@@ -350,10 +366,10 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                 const uint32_t tri = base + __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) + (uint32_t)((m >> lane) & 1ull) - 1u;
                 base += (uint32_t)__popcll(m);
                 const uint32_t p = b * 64u + lane;
-                if (p < total) {
+                if (p < total && (!QW || !quads)) {
                     const uint4* src = &s_flat[wv][tri * 4];
                     const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-                    const uint32_t box = q3.w, k = p - q2.y;
+                    const uint32_t box = q3.w, k = p - (q2.y & 0xFFFFu);
                     const int32_t row = (int32_t)((k * ((box >> 12) & 0x1ffffu)) >> 16);
                     const int32_t col = (int32_t)k - __mul24(row, (int32_t)((box >> 8) & 15u) + 1);
                     const int32_t eb0 = (int32_t)q0.z + __mul24((int32_t)q0.x, col) + __mul24((int32_t)q0.y, row);
@@ -366,6 +382,35 @@ __global__ __launch_bounds__(64 * VIS_WAVES, VIS_OCC) void k_tile_vis(TileParams
                     // negative and NaN patterns are above every non-negative bound)
                     if ((eb0 | eb1 | eb2) >= 0 && __float_as_uint(z) <= zlim)
                         put_fragment<STAIR>(s_key, s_cnt, s_list, (box & 0xffu) + (uint32_t)(row * MTR_BIN + col), make_key(z, q3.z));
+                }
+                if (QW && p < total && quads) {
+                    const uint4* src = &s_flat[wv][tri * 4];
+                    const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+                    const uint32_t box = q3.w, k = p - (q2.y & 0xFFFFu);
+                    const uint32_t bwm1 = (box >> 8) & 15u, bhm1 = q2.y >> 16;
+                    const int32_t qr = (int32_t)((k * ((box >> 12) & 0x1ffffu)) >> 16);
+                    const int32_t qc = (int32_t)k - __mul24(qr, (int32_t)(bwm1 >> 1) + 1);
+                    const int32_t col = qc * 2, row = qr * 2;  // the quad's first pixel in the bbox
+                    const int32_t A0 = (int32_t)q0.x, B0 = (int32_t)q0.y, A1 = (int32_t)q0.w, B1 = (int32_t)q1.x, A2 = (int32_t)q1.z, B2 = (int32_t)q1.w;
+                    const int32_t e0 = (int32_t)q0.z + __mul24(A0, col) + __mul24(B0, row);
+                    const int32_t e1 = (int32_t)q1.y + __mul24(A1, col) + __mul24(B1, row);
+                    const int32_t e2 = (int32_t)q2.x + __mul24(A2, col) + __mul24(B2, row);
+                    const int32_t f1 = (int32_t)((box >> 29) & 1u), f2 = (int32_t)((box >> 30) & 1u);
+                    const float rcp = __uint_as_float(q3.y), dz1 = __uint_as_float(q2.w), dz2 = __uint_as_float(q3.x), z0 = __uint_as_float(q2.z);
+                    const uint32_t pix0 = (box & 0xffu) + (uint32_t)(row * MTR_BIN + col), ordk = q3.z;
+                    // a pixel past the bbox's last column / row belongs to the neighbouring bin (or lies off the target): not ours
+                    const bool vx = (uint32_t)col < bwm1, vy = (uint32_t)row < bhm1;
+                    auto fragment = [&](int32_t a0, int32_t a1, int32_t a2, bool ok, uint32_t pix) {
+                        if (ok && (a0 | a1 | a2) >= 0) {
+                            const float b1 = (float)(a1 + f1) * rcp, b2 = (float)(a2 + f2) * rcp;
+                            const float z = fmaf(b2, dz2, fmaf(b1, dz1, z0));
+                            if (__float_as_uint(z) <= zlim) put_fragment<STAIR>(s_key, s_cnt, s_list, pix, make_key(z, ordk));
+                        }
+                    };
+                    fragment(e0, e1, e2, true, pix0);
+                    fragment(e0 + A0, e1 + A1, e2 + A2, vx, pix0 + 1u);
+                    fragment(e0 + B0, e1 + B1, e2 + B2, vy, pix0 + MTR_BIN);
+                    fragment(e0 + A0 + B0, e1 + A1 + B1, e2 + A2 + B2, vx && vy, pix0 + MTR_BIN + 1u);
                 }
             }
         }
@@ -476,7 +521,13 @@ void mtr_launch_tile_vis(const TileParams& p, bool textured, hipStream_t s) {
     if (p.vis_waves) waves = (int)p.vis_waves;
     else if (mine <= 1536) waves = 8;   // 256 CUs: every bin is resident at once, the heaviest bin bounds the frame
     else if (mine <= 4096) waves = 4;
-#define MTR_LAUNCH_VIS(T, W, S) hipLaunchKernelGGL((mtr::k_tile_vis<T, W, S>), dim3(grid), dim3(64 * W), 0, s, p)
+// QW (2 x 2 quad walk where a pass's boxes are large enough): all-opaque frames that have the GPU to themselves (latency);
+// its own instantiation, so that the kernel of frames in flight keeps its registers and code
+#define MTR_LAUNCH_VIS(T, W, S)                                                                                         \
+    do {                                                                                                                \
+        if (!S && p.quad_walk && MTR_QUAD_WALK) hipLaunchKernelGGL((mtr::k_tile_vis<T, W, false, true>), dim3(grid), dim3(64 * W), 0, s, p);  \
+        else hipLaunchKernelGGL((mtr::k_tile_vis<T, W, S, false>), dim3(grid), dim3(64 * W), 0, s, p);                  \
+    } while (0)
 #define MTR_LAUNCH_VIS_W(T, S) do { if (waves >= 8) MTR_LAUNCH_VIS(T, 8, S); else if (waves >= 4) MTR_LAUNCH_VIS(T, 4, S); else MTR_LAUNCH_VIS(T, 2, S); } while (0)
     // frames with translucent materials keep per-pixel order lists (STAIR); all-opaque frames need only the key
     if (p.mixed) { if (textured) MTR_LAUNCH_VIS_W(true, true); else MTR_LAUNCH_VIS_W(false, true); }

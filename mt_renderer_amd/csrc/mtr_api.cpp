@@ -1866,6 +1866,7 @@ static int32_t run_frame(mtr_frame* f) {
             shared = prev && hipEventQuery(prev) == hipErrorNotReady;
         }
         tp.xcd_run = d->xcd_run != mtr_device::kXcdRunAuto ? d->xcd_run : ((fb.own.world <= 1 && shared) ? std::max(16u, nbx / 4u) : 0u);
+        tp.quad_walk = shared ? 0u : 1u;  // k_tile_vis.hip: shorter alone (latency), slightly slower among other frames' kernels
     }
     if (fb.own.cull && fb.own.own_count) {  // this frame's tile kernel clears the slot's culling counters for the next one
         tp.zero_words = sl.inst_count; tp.zero_nwords = (uint32_t)ndraws * MTR_CULL_CTR_WORDS;

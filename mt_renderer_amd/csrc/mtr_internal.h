@@ -327,6 +327,7 @@ struct TileParams {
     uint32_t* host_status;
     uint32_t vis_waves;  // waves per bin of the visibility kernel (2, 4, 8), 0: the launcher's choice (tuning hook: MTR_VIS_WAVES)
     uint32_t xcd_run;    // bins per run dealt to the XCDs in turn, 0: one contiguous eighth of the bins per XCD (tile_common.h)
+    uint32_t quad_walk;  // visibility kernel: walk bboxes in 2 x 2 quads where a pass's boxes are large enough (a frame alone on the GPU)
     // the slot's culling counters (instance-list and work-list lengths), zeroed here for the slot's next frame
     uint32_t* zero_words;
     uint32_t zero_nwords;
