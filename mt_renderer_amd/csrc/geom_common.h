@@ -659,10 +659,22 @@ __device__ __forceinline__ void emit_bins_unordered(const FrameBuffers& fb, RecH
     //      (the returned count is its place in the group), lane s then reserves queue space for slot s with one
     //      global atomic, and every lane stores its entries: no loop over groups at all. ----
     {
-        const uint32_t lo = wave_pk_minmax<false>(act ? ((uint32_t)h.bx0 | ((uint32_t)h.by0 << 16)) : 0xFFFFFFFFu);
-        const uint32_t hi = wave_pk_minmax<true>(act ? ((uint32_t)h.bx1 | ((uint32_t)h.by1 << 16)) : 0u);
-        const uint32_t wx0 = lo & 0xffffu, wy0 = lo >> 16;
-        if (!__ballot(nb > 4u) && (hi & 0xffffu) - wx0 < 8u && (hi >> 16) - wy0 < 8u) {
+        // The window: a chunk's triangles are neighbours on screen, so try the 8 x 8 bins that start three bins up and left of the
+        // first active lane's rectangle (two v_readlane and a ballot); only when some lane does not fit is the round's true bounding
+        // window worked out (two wave-wide packed min / max reductions, ~36 instructions: what every round used to pay).
+        const uint64_t am = __ballot(act);
+        if (!am) return;
+        const uint32_t fl = (uint32_t)__ffsll((long long)am) - 1u;
+        const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h.bx0, fl), fy = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)h.by0, fl);
+        uint32_t wx0 = fx > 3u ? fx - 3u : 0u, wy0 = fy > 3u ? fy - 3u : 0u;
+        bool fits = !__ballot(act && !((uint32_t)h.bx0 >= wx0 && (uint32_t)h.bx1 < wx0 + 8u && (uint32_t)h.by0 >= wy0 && (uint32_t)h.by1 < wy0 + 8u));
+        if (!fits) {
+            const uint32_t lo = wave_pk_minmax<false>(act ? ((uint32_t)h.bx0 | ((uint32_t)h.by0 << 16)) : 0xFFFFFFFFu);
+            const uint32_t hi = wave_pk_minmax<true>(act ? ((uint32_t)h.bx1 | ((uint32_t)h.by1 << 16)) : 0u);
+            wx0 = lo & 0xffffu; wy0 = lo >> 16;
+            fits = (hi & 0xffffu) - wx0 < 8u && (hi >> 16) - wy0 < 8u;
+        }
+        if (fits && !__ballot(nb > 4u)) {
             const uint32_t w = (uint32_t)(h.bx1 - h.bx0) + 1u;  // 1..4; w >= 3 means a single row
             slot[lane] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
